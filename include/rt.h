@@ -1,0 +1,172 @@
+/*
+ * rt.h — C-ABI of the MI355X-native path tracer (drop-in for the per-pixel ray-trace path of
+ * MaxLayar/Ray-Tracing-Extended).
+ *
+ * The reference tracer sits behind Unity's material-property API; its only caller is
+ * RayTracingManager (Assets/Scripts/RayTracingManager.cs:49-187).  Every entry point below names the
+ * reference call it replaces.  All structs are plain little-endian PODs; buffer strides are the
+ * reference's own Marshal.SizeOf strides (Assets/Scripts/Helpers/ShaderHelper.cs:106,124):
+ *
+ *   RayTracingMaterial 64 B   Assets/Scripts/Data Types/RayTracingMaterial.cs:13-19, RayTracing.shader:67-76
+ *   Sphere             80 B   Assets/Scripts/Data Types/Sphere.cs:5-7,              RayTracing.shader:78-83
+ *   Triangle           72 B   Assets/Scripts/Data Types/Triangle.cs:8-14,           RayTracing.shader:85-89
+ *   MeshInfo           96 B   Assets/Scripts/Data Types/MeshInfo.cs:5-9,            RayTracing.shader:91-98
+ *
+ * No torch / C++ types cross this boundary.  Errors are int status codes (0 = ok); the message of the
+ * last failure is available from rt_last_error().  Nothing throws or aborts across the ABI.
+ * A context is not thread-safe (the reference is single-threaded: Unity main thread in OnRenderImage).
+ * The library is GPU-only: rt_create() fails when no HIP device is present — there is no CPU fallback.
+ */
+#ifndef RT_H_
+#define RT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- buffer element layouts (accepted verbatim from the reference host) ------------------------- */
+
+typedef struct rt_material {            /* 64 B */
+    float   colour[4];
+    float   emissionColour[4];
+    float   specularColour[4];
+    float   emissionStrength;
+    float   smoothness;
+    float   specularProbability;
+    int32_t flag;                       /* 0 None, 1 CheckerPattern, 2 InvisibleLight (RayTracingMaterial.cs:6-11) */
+} rt_material;
+
+typedef struct rt_sphere {              /* 80 B */
+    float       position[3];
+    float       radius;
+    rt_material material;
+} rt_sphere;
+
+typedef struct rt_triangle {            /* 72 B */
+    float posA[3], posB[3], posC[3];
+    float normalA[3], normalB[3], normalC[3];
+} rt_triangle;
+
+typedef struct rt_meshinfo {            /* 96 B */
+    uint32_t    firstTriangleIndex;
+    uint32_t    numTriangles;
+    rt_material material;
+    float       boundsMin[3];
+    float       boundsMax[3];
+} rt_meshinfo;
+
+/* ---- uniforms ------------------------------------------------------------------------------------
+ * One POD holding exactly what RayTracingManager pushes with Material.Set{Int,Float,Vector,Matrix,Color}
+ * (RayTracingManager.cs:113-123,131-132) plus the three Unity built-ins the shader reads
+ * (_ScreenParams.xy, _WorldSpaceCameraPos, _WorldSpaceLightPos0: RayTracing.shader:359,378,247).     */
+
+enum { RT_RNG_PCG = 0 };                /* RayTracing.shader:193-204 (the only parity mode)            */
+enum {
+    RT_INTERSECT_FLAT_CHUNKS = 0,       /* literal reference result: a triangle counts only if its chunk's
+                                           RayBoundingBox test passes (RayTracing.shader:276-294)          */
+    RT_INTERSECT_BRUTE = 1              /* no chunk cull: closest hit over all triangles                  */
+};
+
+typedef struct rt_params {
+    int32_t width, height;              /* _ScreenParams.xy (render-target size)                          */
+    int32_t maxBounceCount;             /* "MaxBounceCount"  (loop is inclusive: B+1 casts, shader :305)  */
+    int32_t numRaysPerPixel;            /* "NumRaysPerPixel"                                             */
+    float   defocusStrength;            /* "DefocusStrength"                                             */
+    float   divergeStrength;            /* "DivergeStrength"                                             */
+    float   viewParams[3];              /* "ViewParams" = (planeWidth, planeHeight, focusDistance)       */
+    float   camLocalToWorld[16];        /* "CamLocalToWorldMatrix", row-major m[row*4+col]               */
+    float   worldSpaceCameraPos[3];     /* _WorldSpaceCameraPos                                          */
+    float   worldSpaceLightPos0[3];     /* _WorldSpaceLightPos0.xyz (= -forward of the directional light) */
+    int32_t environmentEnabled;         /* "EnvironmentEnabled"                                          */
+    float   groundColour[4];            /* "GroundColour"     (already in the space the shader sees)     */
+    float   skyColourHorizon[4];        /* "SkyColourHorizon"                                            */
+    float   skyColourZenith[4];         /* "SkyColourZenith"                                             */
+    float   sunFocus;                   /* "SunFocus"                                                    */
+    float   sunIntensity;               /* "SunIntensity"                                                */
+    int32_t rngMode;                    /* RT_RNG_*                                                      */
+    int32_t intersectMode;              /* RT_INTERSECT_*                                                */
+} rt_params;
+
+/* ---- statistics (the reference exposes numRenderedFrames / numMeshChunks / numTriangles,
+ *      RayTracingManager.cs:25-28,156-157; the work counters are new)                                 */
+typedef struct rt_stats {
+    int32_t  numRenderedFrames;         /* frames accumulated so far                                     */
+    int32_t  numMeshChunks;
+    int32_t  numTriangles;
+    int32_t  numSpheres;
+    int32_t  numBvhNodes;
+    int32_t  bvhMaxStack;               /* worst-case traversal stack depth of the built BVH             */
+    uint64_t rays;                      /* CalculateRayCollision invocations (counting renders only)     */
+    uint64_t sphereTests;
+    uint64_t nodeVisits;                /* BVH nodes fetched                                             */
+    uint64_t triTests;
+    uint64_t hits;                      /* rays that hit something                                       */
+    double   lastKernelMs;              /* HIP-event time of the last trace(+accumulate) launch          */
+    double   totalKernelMs;             /* sum over launches since rt_reset_accum                        */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Lifetime.  Replaces ShaderHelper.InitMaterial / Release (ShaderHelper.cs:147-158,266-289;
+ * RayTracingManager.cs:98-99,190-194).  device = HIP device ordinal.  Returns NULL on failure
+ * (message retrievable with rt_last_error(NULL)).                                                      */
+rt_ctx*     rt_create(int device);
+void        rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Optional: run on a caller-owned hipStream_t (pass as void*).  NULL restores the context's own stream. */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+/* Uniform upload.  Replaces SetShaderParams + UpdateCameraParams (RayTracingManager.cs:111-133).
+ * Changing width/height re-creates (zeroes) the accumulation target, as ShaderHelper.CreateRenderTexture
+ * does (ShaderHelper.cs:186-205).                                                                     */
+int rt_set_params(rt_ctx* ctx, const rt_params* params);
+
+/* Buffer upload = copy (caller may free immediately); n == 0 is legal.  Replaces
+ * ShaderHelper.CreateStructuredBuffer + Material.SetBuffer/SetInt
+ * (RayTracingManager.cs:159-163 "Triangles"/"AllMeshInfo"/"NumMeshes", :184-186 "Spheres"/"NumSpheres").
+ * The library re-lays-out triangles and builds its BVH lazily at the next render.                      */
+int rt_upload_spheres  (rt_ctx* ctx, const rt_sphere*   spheres,  int n);
+int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris,     int n);
+int rt_upload_meshinfo (rt_ctx* ctx, const rt_meshinfo* meshinfo, int n);
+
+/* Row strip rendered by this context: rows [row0, row0+nrows) of the full width x height image.
+ * Seeds use global pixel coordinates (RayTracing.shader:360-362) so the image is decomposition-invariant.
+ * Default = the whole image.                                                                          */
+int rt_set_rows(rt_ctx* ctx, int row0, int nrows);
+
+/* One frame = Graphics.Blit(null, currentFrame, rayTracingMaterial) with "Frame" = frame_index, followed by
+ * the Accumulate blit with "_Frame" = frame_index (RayTracingManager.cs:74-81).  Returns after the
+ * stream has been synchronised.                                                                        */
+int rt_render_frame(rt_ctx* ctx, int frame_index);
+/* n_frames consecutive frames first_frame, first_frame+1, ... (one stream sync at the end).            */
+int rt_render(rt_ctx* ctx, int first_frame, int n_frames);
+/* As rt_render, but a counting build of the same kernel fills rt_stats' work counters.                 */
+int rt_render_counting(rt_ctx* ctx, int first_frame, int n_frames);
+/* Same frame computed by the reference's own flat loop (all spheres, all chunks, all triangles of
+ * passing chunks) on the GPU — a validation/baseline path, not the fast path.                          */
+int rt_render_frame_flat(rt_ctx* ctx, int frame_index);
+
+/* Zero the accumulation target and the frame counter (RayTracingManager.Start, :43-46).                */
+int rt_reset_accum(rt_ctx* ctx);
+
+/* Read back RGBA32F rows of this context's strip (nrows*width*4 floats).  accum = resultTexture,
+ * last_frame = currentFrame (RayTracingManager.cs:33,75).                                             */
+int rt_read_accum     (rt_ctx* ctx, float* rgba, size_t n_floats);
+int rt_read_last_frame(rt_ctx* ctx, float* rgba, size_t n_floats);
+/* Device-side copy of the strip into caller-owned device memory (e.g. a torch tensor handed to RCCL). */
+int rt_copy_accum_to_device(rt_ctx* ctx, void* dst_device_ptr, size_t n_floats);
+
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/* ABI self-description for binding generators / tests. */
+int rt_abi_version(void);
+int rt_sizeof(const char* struct_name);   /* "rt_material" | "rt_sphere" | "rt_triangle" | "rt_meshinfo" | "rt_params" | "rt_stats" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H_ */

@@ -1,0 +1,15 @@
+"""MI355X-native path tracer behind the Ray-Tracing-Extended scene surface.
+
+The directory name carries a hyphen, so import it through `rtx_pkg.load()` (repo root), which registers it as the
+module `rtx_amd`.  Only what the hot path needs lives here:
+
+    csrc/      HIP kernels (gfx950), BVH builder and the C-ABI of include/rt.h  -> librt_mi355x.so
+    _cabi.py   ctypes binding + buffer layouts
+    host.py    mirror of the reference's host components (RayTracingManager, RayTracedSphere, RayTracedMesh ...)
+    scenes.py  synthetic workloads of BASELINE.json configs
+"""
+from . import _cabi, host, scenes  # noqa: F401
+from ._cabi import (MATERIAL, MESHINFO, PARAMS, SPHERE, STATS, TRIANGLE, RT_INTERSECT_BRUTE,  # noqa: F401
+                    RT_INTERSECT_FLAT_CHUNKS, RtError, Tracer, load_library)
+from .host import (Camera, EnvironmentSettings, Light, MaterialFlag, MeshChunk, RayTracedMesh,  # noqa: F401
+                   RayTracedSphere, RayTracingManager, RayTracingMaterial, Transform)

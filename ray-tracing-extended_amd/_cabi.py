@@ -1,0 +1,208 @@
+"""ctypes binding of include/rt.h (the C-ABI of the HIP path tracer) plus the buffer layouts as numpy dtypes.
+
+The layouts are the reference's own GPU-buffer structs (Assets/Scripts/Data Types/RayTracingMaterial.cs:13-19,
+Sphere.cs:5-7, Triangle.cs:8-14, MeshInfo.cs:5-9; strides asserted below: 64 / 80 / 72 / 96 bytes).
+
+There is no CPU fallback: if the HIP library has not been built, or no GPU is present, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+
+# ---- buffer layouts ------------------------------------------------------------------------------------------
+MATERIAL = np.dtype([
+    ("colour", "<f4", 4), ("emissionColour", "<f4", 4), ("specularColour", "<f4", 4),
+    ("emissionStrength", "<f4"), ("smoothness", "<f4"), ("specularProbability", "<f4"), ("flag", "<i4"),
+])
+SPHERE = np.dtype([("position", "<f4", 3), ("radius", "<f4"), ("material", MATERIAL)])
+TRIANGLE = np.dtype([("posA", "<f4", 3), ("posB", "<f4", 3), ("posC", "<f4", 3),
+                     ("normalA", "<f4", 3), ("normalB", "<f4", 3), ("normalC", "<f4", 3)])
+MESHINFO = np.dtype([("firstTriangleIndex", "<u4"), ("numTriangles", "<u4"), ("material", MATERIAL),
+                     ("boundsMin", "<f4", 3), ("boundsMax", "<f4", 3)])
+PARAMS = np.dtype([
+    ("width", "<i4"), ("height", "<i4"), ("maxBounceCount", "<i4"), ("numRaysPerPixel", "<i4"),
+    ("defocusStrength", "<f4"), ("divergeStrength", "<f4"), ("viewParams", "<f4", 3),
+    ("camLocalToWorld", "<f4", 16), ("worldSpaceCameraPos", "<f4", 3), ("worldSpaceLightPos0", "<f4", 3),
+    ("environmentEnabled", "<i4"), ("groundColour", "<f4", 4), ("skyColourHorizon", "<f4", 4),
+    ("skyColourZenith", "<f4", 4), ("sunFocus", "<f4"), ("sunIntensity", "<f4"),
+    ("rngMode", "<i4"), ("intersectMode", "<i4"),
+])
+STATS = np.dtype([
+    ("numRenderedFrames", "<i4"), ("numMeshChunks", "<i4"), ("numTriangles", "<i4"), ("numSpheres", "<i4"),
+    ("numBvhNodes", "<i4"), ("bvhMaxStack", "<i4"),
+    ("rays", "<u8"), ("sphereTests", "<u8"), ("nodeVisits", "<u8"), ("triTests", "<u8"), ("hits", "<u8"),
+    ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"),
+])
+assert MATERIAL.itemsize == 64 and SPHERE.itemsize == 80 and TRIANGLE.itemsize == 72 and MESHINFO.itemsize == 96
+
+RT_INTERSECT_FLAT_CHUNKS = 0
+RT_INTERSECT_BRUTE = 1
+
+# every symbol include/rt.h declares (tests check that the built library exports each one)
+SYMBOLS = [
+    "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_params", "rt_upload_spheres",
+    "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
+    "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
+    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof",
+]
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def load_library() -> ctypes.CDLL:
+    """Load librt_mi355x.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                      "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.rt_create.restype = c_void_p
+    lib.rt_create.argtypes = [c_int]
+    lib.rt_destroy.restype = None
+    lib.rt_destroy.argtypes = [c_void_p]
+    lib.rt_last_error.restype = c_char_p
+    lib.rt_last_error.argtypes = [c_void_p]
+    lib.rt_set_stream.argtypes = [c_void_p, c_void_p]
+    lib.rt_set_params.argtypes = [c_void_p, c_void_p]
+    for n in ("rt_upload_spheres", "rt_upload_triangles", "rt_upload_meshinfo"):
+        getattr(lib, n).argtypes = [c_void_p, c_void_p, c_int]
+    lib.rt_set_rows.argtypes = [c_void_p, c_int, c_int]
+    lib.rt_render_frame.argtypes = [c_void_p, c_int]
+    lib.rt_render_frame_flat.argtypes = [c_void_p, c_int]
+    lib.rt_render.argtypes = [c_void_p, c_int, c_int]
+    lib.rt_render_counting.argtypes = [c_void_p, c_int, c_int]
+    lib.rt_reset_accum.argtypes = [c_void_p]
+    lib.rt_read_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t]
+    lib.rt_read_last_frame.argtypes = [c_void_p, POINTER(c_float), c_size_t]
+    lib.rt_copy_accum_to_device.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.rt_get_stats.argtypes = [c_void_p, c_void_p]
+    lib.rt_abi_version.restype = c_int
+    lib.rt_sizeof.argtypes = [c_char_p]
+    for n in SYMBOLS:
+        f = getattr(lib, n)
+        if f.restype is None or n in ("rt_create", "rt_last_error", "rt_destroy"):
+            continue
+        f.restype = c_int
+    for name, dt in (("rt_material", MATERIAL), ("rt_sphere", SPHERE), ("rt_triangle", TRIANGLE),
+                     ("rt_meshinfo", MESHINFO), ("rt_params", PARAMS), ("rt_stats", STATS)):
+        got = lib.rt_sizeof(name.encode())
+        if got != dt.itemsize:
+            raise RtError(f"ABI mismatch: sizeof({name}) = {got} in the library, {dt.itemsize} in the binding")
+    _lib = lib
+    return lib
+
+
+def _as_buffer(arr, dtype):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    return a, a.ctypes.data_as(c_void_p), int(a.shape[0]) if a.ndim else 0
+
+
+class Tracer:
+    """One rt_ctx.  Thin, exception-raising wrapper; semantics are those documented in include/rt.h."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = self._lib.rt_create(device)
+        if not self._ctx:
+            raise RtError("rt_create failed: " + (self._lib.rt_last_error(None) or b"").decode())
+        self._params = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): " + (self._lib.rt_last_error(self._ctx) or b"").decode())
+
+    # -- uploads
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, dtype=PARAMS).reshape(())
+        self._params = p.copy()
+        self._check(self._lib.rt_set_params(self._ctx, p.ctypes.data_as(c_void_p)), "rt_set_params")
+
+    def upload(self, spheres=None, triangles=None, meshinfo=None):
+        if spheres is not None:
+            a, ptr, n = _as_buffer(spheres, SPHERE)
+            self._check(self._lib.rt_upload_spheres(self._ctx, ptr, n), "rt_upload_spheres")
+        if triangles is not None:
+            a, ptr, n = _as_buffer(triangles, TRIANGLE)
+            self._check(self._lib.rt_upload_triangles(self._ctx, ptr, n), "rt_upload_triangles")
+        if meshinfo is not None:
+            a, ptr, n = _as_buffer(meshinfo, MESHINFO)
+            self._check(self._lib.rt_upload_meshinfo(self._ctx, ptr, n), "rt_upload_meshinfo")
+
+    def set_rows(self, row0: int, nrows: int):
+        self._rows = (row0, nrows)
+        self._check(self._lib.rt_set_rows(self._ctx, row0, nrows), "rt_set_rows")
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.rt_set_stream(self._ctx, c_void_p(stream_ptr)), "rt_set_stream")
+
+    # -- rendering
+    def render_frame(self, frame: int):
+        self._check(self._lib.rt_render_frame(self._ctx, frame), "rt_render_frame")
+
+    def render(self, first_frame: int, n_frames: int):
+        self._check(self._lib.rt_render(self._ctx, first_frame, n_frames), "rt_render")
+
+    def render_counting(self, first_frame: int, n_frames: int):
+        self._check(self._lib.rt_render_counting(self._ctx, first_frame, n_frames), "rt_render_counting")
+
+    def render_frame_flat(self, frame: int):
+        self._check(self._lib.rt_render_frame_flat(self._ctx, frame), "rt_render_frame_flat")
+
+    def reset_accum(self):
+        self._check(self._lib.rt_reset_accum(self._ctx), "rt_reset_accum")
+
+    # -- read-back
+    def _strip_shape(self):
+        W, H = int(self._params["width"]), int(self._params["height"])
+        rows = getattr(self, "_rows", (0, H))[1]
+        return rows, W
+
+    def read_accum(self) -> np.ndarray:
+        rows, W = self._strip_shape()
+        out = np.empty((rows, W, 4), np.float32)
+        self._check(self._lib.rt_read_accum(self._ctx, out.ctypes.data_as(POINTER(c_float)), out.size), "rt_read_accum")
+        return out
+
+    def read_last_frame(self) -> np.ndarray:
+        rows, W = self._strip_shape()
+        out = np.empty((rows, W, 4), np.float32)
+        self._check(self._lib.rt_read_last_frame(self._ctx, out.ctypes.data_as(POINTER(c_float)), out.size), "rt_read_last_frame")
+        return out
+
+    def copy_accum_to_device(self, device_ptr: int, n_floats: int):
+        self._check(self._lib.rt_copy_accum_to_device(self._ctx, c_void_p(device_ptr), n_floats), "rt_copy_accum_to_device")
+
+    def stats(self) -> dict:
+        s = np.zeros((), STATS)
+        self._check(self._lib.rt_get_stats(self._ctx, s.ctypes.data_as(c_void_p)), "rt_get_stats")
+        return {k: s[k].item() for k in STATS.names}

@@ -1,0 +1,211 @@
+// bvh.cpp — binned-SAH binary build, collapsed to 4-wide nodes in breadth-first order (hot upper levels
+// end up contiguous).  See bvh.hpp for why a hierarchy is legal behind the reference's flat chunk loop.
+#include "bvh.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+namespace rtbvh {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset()
+    {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -mn[a]; }
+    }
+    void grow(const float* p)
+    {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    void grow(const Box& b)
+    {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); }
+    }
+    float half_area() const
+    {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (!(dx >= 0.f)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct BNode {            // binary build node
+    Box      box;
+    int32_t  left = -1, right = -1;
+    uint32_t first = 0, count = 0;   // leaf when count > 0
+};
+
+struct Builder {
+    const float* pos; size_t stride; uint32_t n;
+    std::vector<Box>      tbox;
+    std::vector<float>    cent;      // 3 per triangle
+    std::vector<uint32_t> idx;
+    std::vector<BNode>    bn;
+    int depth = 0;
+
+    int build_range(uint32_t first, uint32_t count, int level)
+    {
+        depth = std::max(depth, level);
+        int me = (int)bn.size();
+        bn.emplace_back();
+        Box b; b.reset();
+        Box cb; cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            b.grow(tbox[idx[i]]);
+            cb.grow(&cent[3 * (size_t)idx[i]]);
+        }
+        bn[me].box = b;
+        if (count <= (uint32_t)kMaxLeaf) {
+            bn[me].first = first; bn[me].count = count;
+            return me;
+        }
+        constexpr int NB = 16;
+        int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; ++a) {
+            float lo = cb.mn[a], ext = cb.mx[a] - cb.mn[a];
+            if (!(ext > 0.f)) continue;
+            Box bb[NB]; uint32_t bc[NB];
+            for (int k = 0; k < NB; ++k) { bb[k].reset(); bc[k] = 0; }
+            float scale = (float)NB / ext;
+            for (uint32_t i = first; i < first + count; ++i) {
+                uint32_t t = idx[i];
+                int k = (int)((cent[3 * (size_t)t + a] - lo) * scale);
+                k = std::min(std::max(k, 0), NB - 1);
+                bb[k].grow(tbox[t]); bc[k]++;
+            }
+            float la[NB]; uint32_t lc[NB];
+            Box acc; acc.reset(); uint32_t c = 0;
+            for (int k = 0; k < NB - 1; ++k) { acc.grow(bb[k]); c += bc[k]; la[k] = acc.half_area(); lc[k] = c; }
+            acc.reset(); c = 0;
+            for (int k = NB - 1; k > 0; --k) {
+                acc.grow(bb[k]); c += bc[k];
+                if (lc[k - 1] == 0 || c == 0) continue;
+                float cost = la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)c;
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis >= 0) {
+            float lo = cb.mn[best_axis], scale = (float)NB / (cb.mx[best_axis] - cb.mn[best_axis]);
+            int a = best_axis, s = best_split;
+            auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t t) {
+                int k = (int)((cent[3 * (size_t)t + a] - lo) * scale);
+                k = std::min(std::max(k, 0), NB - 1);
+                return k < s;
+            });
+            mid = (uint32_t)(it - idx.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        } else {
+            mid = first + count / 2;     // all centroids coincide
+        }
+        int l = build_range(first, mid - first, level + 1);
+        int r = build_range(mid, first + count - mid, level + 1);
+        bn[me].left = l; bn[me].right = r;
+        return me;
+    }
+};
+
+// Widen a child box so the slab test stays conservative under float rounding: relative to the magnitude of
+// its own coordinates and, as a floor, to the magnitude G of the whole scene.
+void pad_box(const Box& b, float G, float* mn, float* mx)
+{
+    for (int a = 0; a < 3; ++a) {
+        float m = std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
+        float e = 3e-5f * std::max(m, 0.05f * G) + 1e-30f;
+        mn[a] = b.mn[a] - e;
+        mx[a] = b.mx[a] + e;
+    }
+}
+
+} // namespace
+
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, Bvh& out)
+{
+    out.nodes.clear(); out.order.clear(); out.maxStack = 0; out.depth = 0;
+    if (n_tris == 0) return;
+
+    Builder B; B.pos = tri_pos; B.stride = stride_floats; B.n = n_tris;
+    B.tbox.resize(n_tris); B.cent.resize(3 * (size_t)n_tris); B.idx.resize(n_tris);
+    float G = 0.f;
+    for (uint32_t t = 0; t < n_tris; ++t) {
+        const float* p = tri_pos + (size_t)t * stride_floats;
+        Box b; b.reset(); b.grow(p); b.grow(p + 3); b.grow(p + 6);
+        B.tbox[t] = b;
+        for (int a = 0; a < 3; ++a) {
+            B.cent[3 * (size_t)t + a] = 0.5f * (b.mn[a] + b.mx[a]);
+            G = std::max(G, std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a])));
+        }
+        B.idx[t] = t;
+    }
+    B.bn.reserve(2 * (size_t)n_tris / 2 + 16);
+    int root = B.build_range(0, n_tris, 0);
+    out.order = B.idx;
+    out.depth = B.depth;
+
+    // ---- collapse to 4-wide, breadth-first ----
+    struct Pending { int bnode; uint32_t slot; };
+    std::vector<Node4>& N = out.nodes;
+    std::queue<Pending> q;
+    auto new_node = [&]() -> uint32_t {
+        Node4 z; std::memset(&z, 0, sizeof z);
+        for (int k = 0; k < 4; ++k) {
+            z.child[k] = kEmpty;
+            z.minx[k] = z.miny[k] = z.minz[k] = std::numeric_limits<float>::quiet_NaN();
+            z.maxx[k] = z.maxy[k] = z.maxz[k] = std::numeric_limits<float>::quiet_NaN();
+        }
+        N.push_back(z);
+        return (uint32_t)N.size() - 1u;
+    };
+    q.push({ root, new_node() });
+    while (!q.empty()) {
+        Pending pd = q.front(); q.pop();
+        int kids[4]; int nk = 0;
+        const BNode& r = B.bn[pd.bnode];
+        if (r.count > 0) { kids[nk++] = pd.bnode; }         // the whole mesh fits one leaf
+        else { kids[nk++] = r.left; kids[nk++] = r.right; }
+        while (nk < 4) {                                    // open the internal child with the largest area
+            int pick = -1; float pa = -1.f;
+            for (int k = 0; k < nk; ++k)
+                if (B.bn[kids[k]].count == 0) {
+                    float ar = B.bn[kids[k]].box.half_area();
+                    if (ar > pa) { pa = ar; pick = k; }
+                }
+            if (pick < 0) break;
+            int c = kids[pick];
+            kids[pick] = B.bn[c].left;
+            kids[nk++] = B.bn[c].right;
+        }
+        for (int k = 0; k < nk; ++k) {
+            const BNode& c = B.bn[kids[k]];
+            float mn[3], mx[3];
+            pad_box(c.box, G, mn, mx);
+            uint32_t ref;
+            if (c.count > 0) ref = make_leaf(c.first, c.count);
+            else { ref = new_node(); q.push({ kids[k], ref }); }
+            Node4& me = N[pd.slot];                          // (re-fetch: new_node may reallocate)
+            me.minx[k] = mn[0]; me.miny[k] = mn[1]; me.minz[k] = mn[2];
+            me.maxx[k] = mx[0]; me.maxy[k] = mx[1]; me.maxz[k] = mx[2];
+            me.child[k] = ref;
+        }
+        N[pd.slot].meta[0] = (uint32_t)nk;
+    }
+
+    // ---- worst-case traversal stack: at a node with k used slots the nearest child becomes current and up
+    // to k-1 are pushed; nodes are in BFS order so children have larger indices -> sweep backwards.
+    std::vector<int> need(N.size(), 0);
+    for (size_t i = N.size(); i-- > 0;) {
+        int k = (int)N[i].meta[0], deepest = 0;
+        for (int s = 0; s < k; ++s) {
+            uint32_t c = N[i].child[s];
+            if (!(c & kLeafBit)) deepest = std::max(deepest, need[c]);
+        }
+        need[i] = (k - 1) + deepest;
+    }
+    out.maxStack = std::max(1, need[0]);
+}
+
+} // namespace rtbvh

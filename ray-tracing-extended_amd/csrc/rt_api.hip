@@ -1,0 +1,408 @@
+// rt_api.hip — C-ABI of include/rt.h on top of the HIP kernels (gfx950 only, no CPU fallback).
+//
+// Host-side counterpart of RayTracingManager.OnRenderImage / InitFrame (RayTracingManager.cs:49-124) below
+// the Material.Set* / Graphics.Blit boundary: owns the device copies of the three structured buffers, the
+// accumulation target (resultTexture) and the per-frame target (currentFrame).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define RT_HIP(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(ctx, -100, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = std::max<size_t>(n, 1);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    rt_params params{};
+    bool have_params = false;
+    int row0 = 0, nrows = -1;           // -1: whole image
+
+    std::vector<rt_sphere>   h_spheres;
+    std::vector<rt_triangle> h_tris;
+    std::vector<rt_meshinfo> h_mesh;
+    bool scene_dirty = true;
+
+    DevBuf<float4> d_sph_geom, d_sph_mat, d_nodes, d_tri_geo, d_tri_nrm, d_chunk_mat, d_chunk_box;
+    DevBuf<float>  d_raw_tris;
+    DevBuf<uint32_t> d_raw_range;
+    DevBuf<float4> d_frame, d_accum;
+    size_t target_pixels = 0;
+    int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0;
+    unsigned int* d_tile_counter = nullptr;
+    unsigned long long* d_counters = nullptr;
+
+    rtbvh::Bvh bvh;
+    int n_cu = 0;
+    rt_stats stats{};
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+inline float4 f4(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
+inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+void pack_material(const rt_material& m, float4* out)
+{
+    out[0] = f4(m.colour); out[1] = f4(m.emissionColour); out[2] = f4(m.specularColour);
+    out[3] = make_float4(m.emissionStrength, m.smoothness, m.specularProbability, u2f((uint32_t)m.flag));
+}
+
+// Re-layout of the uploaded buffers + BVH build.  Edge vectors and their cross product are the operands of
+// RayTriangle (RayTracing.shader:152-154) evaluated once here with the same float operations.
+int build_scene(rt_ctx* c)
+{
+    const size_t ns = c->h_spheres.size(), nt = c->h_tris.size(), nm = c->h_mesh.size();
+    if (nt > (1u << 28)) return fail(c, -3, "too many triangles (%zu)", nt);
+    // triangle -> chunk map; every triangle the shader can reach belongs to exactly the chunk ranges given
+    std::vector<uint32_t> chunk_of(nt, 0xFFFFFFFFu);
+    for (size_t m = 0; m < nm; ++m) {
+        const rt_meshinfo& mi = c->h_mesh[m];
+        if ((uint64_t)mi.firstTriangleIndex + mi.numTriangles > nt)
+            return fail(c, -4, "meshinfo[%zu] addresses triangles [%u,%u) beyond the %zu uploaded", m,
+                        mi.firstTriangleIndex, mi.firstTriangleIndex + mi.numTriangles, nt);
+        for (uint32_t i = 0; i < mi.numTriangles; ++i) {
+            uint32_t& slot = chunk_of[mi.firstTriangleIndex + i];
+            if (slot != 0xFFFFFFFFu)
+                return fail(c, -5, "triangle %u is referenced by chunks %u and %zu (overlapping chunk ranges are not supported)",
+                            mi.firstTriangleIndex + i, slot, m);
+            slot = (uint32_t)m;
+        }
+    }
+    // triangles outside every chunk are never visited by the shader: leave them out of the hierarchy
+    std::vector<uint32_t> live; live.reserve(nt);
+    for (size_t t = 0; t < nt; ++t) if (chunk_of[t] != 0xFFFFFFFFu) live.push_back((uint32_t)t);
+    std::vector<float> pos(9 * live.size());
+    for (size_t i = 0; i < live.size(); ++i) std::memcpy(&pos[9 * i], c->h_tris[live[i]].posA, 36);
+    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), c->bvh);
+
+    const size_t nl = live.size();
+    std::vector<float4> geo(3 * nl), nrm(3 * nl);
+    for (size_t i = 0; i < nl; ++i) {
+        const uint32_t orig = live[c->bvh.order[i]];
+        const rt_triangle& t = c->h_tris[orig];
+        const float ex = t.posB[0] - t.posA[0], ey = t.posB[1] - t.posA[1], ez = t.posB[2] - t.posA[2];
+        const float fx = t.posC[0] - t.posA[0], fy = t.posC[1] - t.posA[1], fz = t.posC[2] - t.posA[2];
+        const float nx = ey * fz - ez * fy, ny = ez * fx - ex * fz, nz = ex * fy - ey * fx;
+        geo[3 * i + 0] = make_float4(t.posA[0], t.posA[1], t.posA[2], ex);
+        geo[3 * i + 1] = make_float4(ey, ez, fx, fy);
+        geo[3 * i + 2] = make_float4(fz, nx, ny, nz);
+        nrm[3 * i + 0] = make_float4(t.normalA[0], t.normalA[1], t.normalA[2], u2f(chunk_of[orig]));
+        nrm[3 * i + 1] = make_float4(t.normalB[0], t.normalB[1], t.normalB[2], u2f(orig));
+        nrm[3 * i + 2] = make_float4(t.normalC[0], t.normalC[1], t.normalC[2], 0.f);
+    }
+    std::vector<float4> sg(ns), sm(4 * ns), cm(4 * nm), cb(2 * nm);
+    for (size_t i = 0; i < ns; ++i) {
+        const rt_sphere& s = c->h_spheres[i];
+        sg[i] = make_float4(s.position[0], s.position[1], s.position[2], s.radius);
+        pack_material(s.material, &sm[4 * i]);
+    }
+    std::vector<uint32_t> range(2 * nm);
+    for (size_t m = 0; m < nm; ++m) {
+        const rt_meshinfo& mi = c->h_mesh[m];
+        pack_material(mi.material, &cm[4 * m]);
+        cb[2 * m]     = make_float4(mi.boundsMin[0], mi.boundsMin[1], mi.boundsMin[2], 0.f);
+        cb[2 * m + 1] = make_float4(mi.boundsMax[0], mi.boundsMax[1], mi.boundsMax[2], 0.f);
+        range[2 * m] = mi.firstTriangleIndex; range[2 * m + 1] = mi.numTriangles;
+    }
+
+#define RT_UP(buf, vec, T)                                                                                  \
+    RT_HIP(c, buf.ensure(vec.size()));                                                                      \
+    if (!vec.empty()) RT_HIP(c, hipMemcpyAsync(buf.p, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    RT_UP(c->d_sph_geom, sg, float4) RT_UP(c->d_sph_mat, sm, float4)
+    RT_UP(c->d_tri_geo, geo, float4) RT_UP(c->d_tri_nrm, nrm, float4)
+    RT_UP(c->d_chunk_mat, cm, float4) RT_UP(c->d_chunk_box, cb, float4)
+    RT_UP(c->d_raw_range, range, uint32_t)
+    RT_HIP(c, c->d_nodes.ensure(c->bvh.nodes.size() * 8));
+    if (!c->bvh.nodes.empty())
+        RT_HIP(c, hipMemcpyAsync(c->d_nodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node4),
+                                 hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, c->d_raw_tris.ensure(nt * 18));
+    if (nt) RT_HIP(c, hipMemcpyAsync(c->d_raw_tris.p, c->h_tris.data(), nt * sizeof(rt_triangle), hipMemcpyHostToDevice, c->stream));
+#undef RT_UP
+    RT_HIP(c, hipStreamSynchronize(c->stream));     // host staging vectors die here
+
+    c->stats.numSpheres = (int)ns; c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
+    c->stats.numBvhNodes = (int)c->bvh.nodes.size(); c->stats.bvhMaxStack = c->bvh.maxStack;
+    c->scene_dirty = false;
+    return 0;
+}
+
+int ensure_targets(rt_ctx* c)
+{
+    const int W = c->params.width, H = c->params.height;
+    const int r0 = c->nrows < 0 ? 0 : c->row0, nr = c->nrows < 0 ? H : c->nrows;
+    if (r0 < 0 || nr < 0 || r0 + nr > H) return fail(c, -6, "row strip [%d,%d) outside image height %d", r0, r0 + nr, H);
+    if (W == c->target_w && H == c->target_h && r0 == c->target_row0 && nr == c->target_rows) return 0;
+    const size_t px = (size_t)W * nr;
+    RT_HIP(c, c->d_frame.ensure(px));
+    RT_HIP(c, c->d_accum.ensure(px));
+    // a re-created render texture starts cleared (ShaderHelper.CreateRenderTexture, ShaderHelper.cs:186-205)
+    if (px) {
+        RT_HIP(c, hipMemsetAsync(c->d_frame.p, 0, px * sizeof(float4), c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, px * sizeof(float4), c->stream));
+    }
+    c->target_pixels = px; c->target_w = W; c->target_h = H; c->target_row0 = r0; c->target_rows = nr;
+    c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0;
+    return 0;
+}
+
+enum class Variant { Fast, Counting, Flat };
+
+int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
+{
+    if (!c) return -1;
+    if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
+    if (n_frames < 0) return fail(c, -2, "n_frames < 0");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
+    { int r = ensure_targets(c); if (r) return r; }
+    if (c->target_pixels == 0 || n_frames == 0) return 0;
+
+    rtk::DeviceScene S{};
+    S.sph_geom = c->d_sph_geom.p; S.sph_mat = c->d_sph_mat.p; S.nodes = c->d_nodes.p;
+    S.tri_geo = c->d_tri_geo.p; S.tri_nrm = c->d_tri_nrm.p; S.chunk_mat = c->d_chunk_mat.p; S.chunk_box = c->d_chunk_box.p;
+    S.raw_tris = c->d_raw_tris.p; S.raw_chunk_range = c->d_raw_range.p;
+    S.ns = (int)c->h_spheres.size(); S.nn = (int)c->bvh.nodes.size(); S.nt = (int)c->h_tris.size(); S.nm = (int)c->h_mesh.size();
+
+    rtk::FrameArgs F{};
+    F.p = c->params;
+    F.row0 = c->target_row0; F.nrows = c->target_rows;
+    F.tiles_x = (c->target_w + 7) / 8; F.tiles_y = (c->target_rows + 7) / 8;
+    F.stack_cap = std::max(1, c->bvh.maxStack);
+    F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
+    F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
+
+    const size_t lds = var == Variant::Flat ? 0 : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
+    if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
+    const void* fn = var == Variant::Fast ? (const void*)rtk::k_trace<false, false>
+                   : var == Variant::Counting ? (const void*)rtk::k_trace<true, false>
+                                              : (const void*)rtk::k_trace<false, true>;
+    if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::kBlock, lds));
+    if (per_cu < 1) return fail(c, -7, "kernel does not fit a CU (LDS %zu B)", lds);
+    const int ntiles = F.tiles_x * F.tiles_y;
+    const int want = (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
+    const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
+
+    if (var == Variant::Counting) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 5 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < n_frames; ++i) {
+        F.frame = first_frame + i;
+        RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+        switch (var) {
+        case Variant::Fast:     hipLaunchKernelGGL((rtk::k_trace<false, false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F); break;
+        case Variant::Counting: hipLaunchKernelGGL((rtk::k_trace<true, false>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F); break;
+        case Variant::Flat:     hipLaunchKernelGGL((rtk::k_trace<false, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F); break;
+        }
+        RT_HIP(c, hipGetLastError());
+    }
+    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    RT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->stats.lastKernelMs = ms; c->stats.totalKernelMs += ms;
+    c->stats.numRenderedFrames += n_frames;
+    if (var == Variant::Counting) {
+        unsigned long long h[5];
+        RT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+        c->stats.rays = h[0]; c->stats.sphereTests = h[1]; c->stats.nodeVisits = h[2]; c->stats.triTests = h[3]; c->stats.hits = h[4];
+    }
+    return 0;
+}
+
+int read_target(rt_ctx* c, bool accum, float* dst, size_t n_floats, bool to_device)
+{
+    if (!c) return -1;
+    if (!dst && n_floats) return fail(c, -2, "null destination");
+    if (c->have_params) { int r = ensure_targets(c); if (r) return r; }
+    if (n_floats != c->target_pixels * 4)
+        return fail(c, -2, "expected %zu floats (rows*width*4), got %zu", c->target_pixels * 4, n_floats);
+    if (!n_floats) return 0;
+    RT_HIP(c, hipSetDevice(c->device));
+    const float4* src = accum ? c->d_accum.p : c->d_frame.p;
+    RT_HIP(c, hipMemcpyAsync(dst, src, n_floats * sizeof(float), to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return 1; }
+
+int rt_sizeof(const char* name)
+{
+    if (!name) return -1;
+    if (!std::strcmp(name, "rt_material")) return (int)sizeof(rt_material);
+    if (!std::strcmp(name, "rt_sphere"))   return (int)sizeof(rt_sphere);
+    if (!std::strcmp(name, "rt_triangle")) return (int)sizeof(rt_triangle);
+    if (!std::strcmp(name, "rt_meshinfo")) return (int)sizeof(rt_meshinfo);
+    if (!std::strcmp(name, "rt_params"))   return (int)sizeof(rt_params);
+    if (!std::strcmp(name, "rt_stats"))    return (int)sizeof(rt_stats);
+    return -1;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+rt_ctx* rt_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(nullptr, -1, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count = 0" : hipGetErrorString(e)); return nullptr; }
+    if (device < 0 || device >= n) { fail(nullptr, -1, "device %d out of range [0,%d)", device, n); return nullptr; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { fail(nullptr, -1, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { fail(nullptr, -1, "hipGetDeviceProperties: %s", hipGetErrorString(e)); delete c; return nullptr; }
+    c->n_cu = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess
+        || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess
+        || (e = hipMalloc((void**)&c->d_tile_counter, sizeof(unsigned int))) != hipSuccess
+        || (e = hipMalloc((void**)&c->d_counters, 5 * sizeof(unsigned long long))) != hipSuccess) {
+        fail(nullptr, -1, "context setup: %s", hipGetErrorString(e));
+        rt_destroy(c);
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    return c;
+}
+
+void rt_destroy(rt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
+    c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
+    c->d_frame.release(); c->d_accum.release();
+    if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rt_set_stream(rt_ctx* c, void* hip_stream)
+{
+    if (!c) return -1;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+int rt_set_params(rt_ctx* c, const rt_params* p)
+{
+    if (!c) return -1;
+    if (!p) return fail(c, -2, "null params");
+    if (p->width < 0 || p->height < 0 || (int64_t)p->width * p->height > (int64_t)1 << 31) return fail(c, -2, "bad target size %dx%d", p->width, p->height);
+    if (p->numRaysPerPixel < 0) return fail(c, -2, "numRaysPerPixel < 0");
+    if (p->rngMode != RT_RNG_PCG) return fail(c, -2, "unknown rngMode %d", p->rngMode);
+    if (p->intersectMode != RT_INTERSECT_FLAT_CHUNKS && p->intersectMode != RT_INTERSECT_BRUTE) return fail(c, -2, "unknown intersectMode %d", p->intersectMode);
+    c->params = *p; c->have_params = true;
+    return 0;
+}
+
+int rt_upload_spheres(rt_ctx* c, const rt_sphere* s, int n)
+{
+    if (!c) return -1;
+    if (n < 0 || (n > 0 && !s)) return fail(c, -2, "bad sphere upload (n=%d)", n);
+    c->h_spheres.assign(s, s + n); c->scene_dirty = true;
+    return 0;
+}
+int rt_upload_triangles(rt_ctx* c, const rt_triangle* t, int n)
+{
+    if (!c) return -1;
+    if (n < 0 || (n > 0 && !t)) return fail(c, -2, "bad triangle upload (n=%d)", n);
+    c->h_tris.assign(t, t + n); c->scene_dirty = true;
+    return 0;
+}
+int rt_upload_meshinfo(rt_ctx* c, const rt_meshinfo* m, int n)
+{
+    if (!c) return -1;
+    if (n < 0 || (n > 0 && !m)) return fail(c, -2, "bad meshinfo upload (n=%d)", n);
+    c->h_mesh.assign(m, m + n); c->scene_dirty = true;
+    return 0;
+}
+
+int rt_set_rows(rt_ctx* c, int row0, int nrows)
+{
+    if (!c) return -1;
+    if (row0 < 0 || nrows < 0) return fail(c, -2, "bad row strip (%d,%d)", row0, nrows);
+    c->row0 = row0; c->nrows = nrows;
+    return 0;
+}
+
+int rt_render_frame(rt_ctx* c, int frame_index) { return launch_frames(c, frame_index, 1, Variant::Fast); }
+int rt_render(rt_ctx* c, int first_frame, int n_frames) { return launch_frames(c, first_frame, n_frames, Variant::Fast); }
+int rt_render_counting(rt_ctx* c, int first_frame, int n_frames) { return launch_frames(c, first_frame, n_frames, Variant::Counting); }
+int rt_render_frame_flat(rt_ctx* c, int frame_index) { return launch_frames(c, frame_index, 1, Variant::Flat); }
+
+int rt_reset_accum(rt_ctx* c)
+{
+    if (!c) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (c->target_pixels) {
+        RT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, c->target_pixels * sizeof(float4), c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_frame.p, 0, c->target_pixels * sizeof(float4), c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0;
+    return 0;
+}
+
+int rt_read_accum(rt_ctx* c, float* rgba, size_t n) { return read_target(c, true, rgba, n, false); }
+int rt_read_last_frame(rt_ctx* c, float* rgba, size_t n) { return read_target(c, false, rgba, n, false); }
+int rt_copy_accum_to_device(rt_ctx* c, void* dst, size_t n) { return read_target(c, true, (float*)dst, n, true); }
+
+int rt_get_stats(rt_ctx* c, rt_stats* out)
+{
+    if (!c) return -1;
+    if (!out) return fail(c, -2, "null stats");
+    *out = c->stats;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,417 @@
+// rt_kernels.hpp — the CDNA4 path-trace megakernel and its validation twin.
+//
+// Path replaced: RayTracing.shader `frag` (:356-389) -> `Trace` (:300-352) -> `CalculateRayCollision`
+// (:256-297) -> RaySphere / RayTriangle / RayBoundingBox (:120-187), followed by Accumulate.shader `frag`
+// (:43-54), i.e. the two material blits of RayTracingManager.OnRenderImage (RayTracingManager.cs:74-81).
+//
+// Execution model (wave64, gfx950):
+//   * one lane = one pixel, one wave = one 8x8 pixel tile; waves are persistent and pull tiles from an
+//     atomic queue (wave granularity, no workgroup barrier anywhere);
+//   * the PCG state of a pixel is a serial chain over all samples and bounces (RayTracing.shader:362,374-385),
+//     so a lane keeps its pixel for the whole frame; inside the frame the lane runs a flat state machine —
+//     every loop iteration is exactly one CalculateRayCollision plus its shading, and a lane whose path ended
+//     immediately starts the pixel's next sample instead of idling until its neighbours finish theirs;
+//   * closest hit = uniform sphere loop (scalar loads) + 4-wide BVH traversal, "while-while" shaped: lanes
+//     descend internal nodes until each holds a leaf, then the wave tests leaves together.  The per-lane
+//     traversal stack lives in LDS (stack[entry][lane], one bank per lane, conflict-free);
+//   * accumulate (Accumulate.shader:43-54) is fused into the epilogue: 16 B read + 2 x 16 B write per pixel.
+#pragma once
+#include "rt_math.hpp"
+#include "bvh.hpp"
+#include "../../include/rt.h"
+
+namespace rtk {
+
+using rtm::v3;
+
+struct DeviceScene {
+    const float4* sph_geom;     // [ns]      (centre.xyz, radius)                         16 B
+    const float4* sph_mat;      // [ns*4]    rt_material as 4 float4                      64 B
+    const float4* nodes;        // [nn*8]    rtbvh::Node4                                128 B
+    const float4* tri_geo;      // [nt*3]    BVH order: (A, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz) 48 B
+    const float4* tri_nrm;      // [nt*3]    BVH order: (nA, chunk) (nB, orig index) (nC, -)   48 B
+    const float4* chunk_mat;    // [nm*4]    rt_material of the chunk                     64 B
+    const float4* chunk_box;    // [nm*2]    (boundsMin, -) (boundsMax, -)                32 B
+    // raw reference buffers for the flat validation kernel
+    const float*  raw_tris;     // [nt*18]
+    const uint32_t* raw_chunk_range; // [nm*2] first, count
+    int ns, nn, nt, nm;
+};
+
+struct FrameArgs {
+    rt_params p;
+    int frame;
+    int row0, nrows;            // strip of the full image rendered by this launch
+    int tiles_x, tiles_y;
+    int stack_cap;              // LDS stack entries per lane
+    float4* out_frame;          // [nrows*W] currentFrame
+    float4* accum;              // [nrows*W] resultTexture
+    unsigned int* tile_counter;
+    unsigned long long* counters;   // [5] rays, sphereTests, nodeVisits, triTests, hits
+};
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kTriBit = 0x80000000u;
+
+struct Hit {
+    float    t;
+    uint32_t id;      // kNone | sphere index | kTriBit + triangle index in BVH order
+    float    u, v;    // barycentrics of the winning triangle
+};
+
+struct Counters { uint32_t rays, sph, nodes, tris, hits; };
+
+__device__ __forceinline__ v3 ld3(const float* p) { return rtm::mk(p[0], p[1], p[2]); }
+
+// RayBoundingBox — RayTracing.shader:177-187, literal arithmetic (used for the chunk filter)
+__device__ __forceinline__ bool ray_bounding_box(v3 o, v3 inv, v3 bmin, v3 bmax)
+{
+    float tminx = (bmin.x - o.x) * inv.x, tminy = (bmin.y - o.y) * inv.y, tminz = (bmin.z - o.z) * inv.z;
+    float tmaxx = (bmax.x - o.x) * inv.x, tmaxy = (bmax.y - o.y) * inv.y, tmaxz = (bmax.z - o.z) * inv.z;
+    float t1x = rtm::fmin_(tminx, tmaxx), t1y = rtm::fmin_(tminy, tmaxy), t1z = rtm::fmin_(tminz, tmaxz);
+    float t2x = rtm::fmax_(tminx, tmaxx), t2y = rtm::fmax_(tminy, tmaxy), t2z = rtm::fmax_(tminz, tmaxz);
+    float tNear = rtm::fmax_(rtm::fmax_(t1x, t1y), t1z);
+    float tFar  = rtm::fmin_(rtm::fmin_(t2x, t2y), t2z);
+    return tNear <= tFar;
+}
+
+// RaySphere — RayTracing.shader:120-146
+__device__ __forceinline__ bool ray_sphere(v3 o, v3 d, float a, v3 centre, float radius, float& dst)
+{
+    v3 oc = o - centre;
+    float b = 2.0f * rtm::dot(oc, d);
+    float c = rtm::dot(oc, oc) - radius * radius;
+    float disc = b * b - 4.0f * a * c;
+    if (disc >= 0.0f) {
+        dst = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        return dst >= 0.0f;
+    }
+    return false;
+}
+
+// RayTriangle — RayTracing.shader:150-174 with edgeAB, edgeAC and their cross product precomputed on the host
+// by the same float operations (upload re-layout).
+__device__ __forceinline__ bool ray_triangle(v3 o, v3 d, v3 A, v3 eAB, v3 eAC, v3 n, float& dst, float& u, float& v)
+{
+    v3 ao = o - A;
+    v3 dao = rtm::cross(ao, d);
+    float det = -rtm::dot(d, n);
+    float inv = 1.0f / det;
+    dst = rtm::dot(ao, n) * inv;
+    u = rtm::dot(eAC, dao) * inv;
+    v = -rtm::dot(eAB, dao) * inv;
+    float w = 1.0f - u - v;
+    return det >= 1e-6f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+}
+
+// ---- closest hit: spheres, then BVH ---------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_mode, v3 o, v3 d,
+                                           uint32_t* stk, Counters& cnt)
+{
+    Hit best; best.t = __builtin_inff(); best.id = kNone; best.u = 0.f; best.v = 0.f;
+    if (COUNT) cnt.rays++;
+
+    // CalculateRayCollision :263-273 — buffer order, strict '<' (first sphere wins ties)
+    const float a = rtm::dot(d, d);
+    for (int i = 0; i < S.ns; ++i) {
+        float4 s = S.sph_geom[i];
+        float dst;
+        if (COUNT) cnt.sph++;
+        if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+    }
+
+    if (S.nn > 0) {
+        const v3 inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);     // RayBoundingBox :179
+        int sp = 0;
+        uint32_t cur = 0;                                               // root
+        while (cur != kNone) {
+            // ---- descend internal nodes until this lane holds a leaf (or ran dry)
+            while ((int)cur >= 0) {
+                if (COUNT) cnt.nodes++;
+                const float4* nb = S.nodes + (size_t)cur * 8;
+                const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
+                const uint4 ch = *reinterpret_cast<const uint4*>(nb + 6);
+                float t0, t1, t2, t3;
+                uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define RT_SLAB(K, TK, CK)                                                                           \
+                {                                                                                            \
+                    float ax = (mnx.K - o.x) * inv.x, bx = (mxx.K - o.x) * inv.x;                            \
+                    float ay = (mny.K - o.y) * inv.y, by = (mxy.K - o.y) * inv.y;                            \
+                    float az = (mnz.K - o.z) * inv.z, bz = (mxz.K - o.z) * inv.z;                            \
+                    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), \
+                                               __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));             \
+                    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), \
+                                               __builtin_fminf(__builtin_fmaxf(az, bz), best.t));           \
+                    TK = (tn <= tf && CK != kNone) ? tn : __builtin_inff();                                  \
+                }
+                RT_SLAB(x, t0, c0) RT_SLAB(y, t1, c1) RT_SLAB(z, t2, c2) RT_SLAB(w, t3, c3)
+#undef RT_SLAB
+                // sort the four (t, child) pairs ascending: 5-exchange network
+#define RT_CSWAP(TA, CA, TB, CB) { bool s_ = TB < TA; float tt_ = s_ ? TB : TA; float tu_ = s_ ? TA : TB;         \
+                                   uint32_t ct_ = s_ ? CB : CA; uint32_t cu_ = s_ ? CA : CB; TA = tt_; TB = tu_; CA = ct_; CB = cu_; }
+                RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
+                RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2)
+#undef RT_CSWAP
+                const float INF = __builtin_inff();
+                if (t3 < INF) { stk[sp * 64] = c3; ++sp; }
+                if (t2 < INF) { stk[sp * 64] = c2; ++sp; }
+                if (t1 < INF) { stk[sp * 64] = c1; ++sp; }
+                if (t0 < INF) cur = c0;
+                else if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                else cur = kNone;
+            }
+            // ---- leaf
+            if (cur != kNone) {
+                const uint32_t first = (cur & 0x7FFFFFFFu) >> 2, count = (cur & 3u) + 1u;
+                for (uint32_t j = 0; j < count; ++j) {
+                    const uint32_t ti = first + j;
+                    const float4* tg = S.tri_geo + (size_t)ti * 3;
+                    const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                    float dst, u, v;
+                    if (COUNT) cnt.tris++;
+                    bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
+                                            rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
+                    if (hit && dst <= best.t) {
+                        bool take = dst < best.t;
+                        if (!take && (best.id & kTriBit) && best.id != kNone) {
+                            // equal dst: the reference keeps the triangle that comes first in the buffer
+                            uint32_t oc = __float_as_uint(S.tri_nrm[(size_t)ti * 3 + 1].w);
+                            uint32_t ob = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3 + 1].w);
+                            take = oc < ob;
+                        }
+                        if (take && intersect_mode == RT_INTERSECT_FLAT_CHUNKS) {
+                            // the reference only reaches this triangle if its chunk's box test passes (:279)
+                            uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
+                            float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
+                            take = ray_bounding_box(o, inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
+                        }
+                        if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
+                    }
+                }
+                if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                else cur = kNone;
+            }
+        }
+    }
+    if (COUNT && best.id != kNone) cnt.hits++;
+    return best;
+}
+
+// ---- the reference's own flat loop (validation twin): every lane walks all chunks / triangles ------------
+__device__ __forceinline__ Hit closest_hit_flat(const DeviceScene& S, int intersect_mode, v3 o, v3 d,
+                                                v3& nrm_out, uint32_t& chunk_out)
+{
+    Hit best; best.t = __builtin_inff(); best.id = kNone; best.u = 0.f; best.v = 0.f;
+    const float a = rtm::dot(d, d);
+    for (int i = 0; i < S.ns; ++i) {
+        float4 s = S.sph_geom[i];
+        float dst;
+        if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+    }
+    const v3 inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    nrm_out = rtm::mk(0.f, 0.f, 0.f); chunk_out = 0;
+    for (int m = 0; m < S.nm; ++m) {
+        if (intersect_mode == RT_INTERSECT_FLAT_CHUNKS) {
+            float4 bmn = S.chunk_box[(size_t)m * 2], bmx = S.chunk_box[(size_t)m * 2 + 1];
+            if (!ray_bounding_box(o, inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z))) continue;
+        }
+        const uint32_t first = S.raw_chunk_range[2 * m], count = S.raw_chunk_range[2 * m + 1];
+        for (uint32_t j = 0; j < count; ++j) {
+            const float* t = S.raw_tris + (size_t)(first + j) * 18;
+            v3 A = ld3(t), eAB = ld3(t + 3) - A, eAC = ld3(t + 6) - A;
+            v3 n = rtm::cross(eAB, eAC);
+            float dst, u, v;
+            if (ray_triangle(o, d, A, eAB, eAC, n, dst, u, v) && dst < best.t) {
+                best.t = dst; best.id = kTriBit | (first + j); best.u = u; best.v = v;
+                float w = 1.0f - u - v;
+                nrm_out = (ld3(t + 9) * w + ld3(t + 12) * u) + ld3(t + 15) * v;
+                chunk_out = (uint32_t)m;
+            }
+        }
+    }
+    return best;
+}
+
+// GetEnvironmentLight — RayTracing.shader:238-251
+__device__ __forceinline__ v3 environment_light(const rt_params& p, v3 d)
+{
+    if (!p.environmentEnabled) return rtm::mk(0.f, 0.f, 0.f);
+    float skyGradientT = rtm::pow_(rtm::smoothstep(0.0f, 0.4f, d.y), 0.35f);
+    float groundToSkyT = rtm::smoothstep(-0.01f, 0.0f, d.y);
+    v3 skyGradient = rtm::lerp(ld3(p.skyColourHorizon), ld3(p.skyColourZenith), skyGradientT);
+    float sun = rtm::pow_(rtm::fmax_(0.0f, rtm::dot(d, ld3(p.worldSpaceLightPos0))), p.sunFocus) * p.sunIntensity;
+    v3 composite = rtm::lerp(ld3(p.groundColour), skyGradient, groundToSkyT);
+    float sunTerm = sun * ((groundToSkyT >= 1.0f) ? 1.0f : 0.0f);
+    return rtm::mk(composite.x + sunTerm, composite.y + sunTerm, composite.z + sunTerm);
+}
+
+__device__ __forceinline__ float mod2(float x) { return x - 2.0f * __builtin_floorf(x / 2.0f); }
+
+struct Camera { v3 focusPoint, right, up, pos; float W; };
+
+// frag :377-382 — one camera ray (4 RNG draws)
+__device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, uint32_t& rng, v3& o, v3& d)
+{
+    float jx, jy;
+    rtm::random_point_in_circle(rng, jx, jy);
+    jx = jx * p.defocusStrength / c.W; jy = jy * p.defocusStrength / c.W;
+    o = (c.pos + c.right * jx) + c.up * jy;
+    rtm::random_point_in_circle(rng, jx, jy);
+    jx = jx * p.divergeStrength / c.W; jy = jy * p.divergeStrength / c.W;
+    v3 jfp = (c.focusPoint + c.right * jx) + c.up * jy;
+    d = rtm::normalize(jfp - o);
+}
+
+// One pixel of one frame: frag :356-389 as a flat state machine (see file header).
+template <bool COUNT, bool FLAT>
+__device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, int frame, int x, int y,
+                                           uint32_t* stk, Counters& cnt)
+{
+    const float* M = p.camLocalToWorld;
+    const uint32_t W = (uint32_t)p.width;
+    Camera cam;
+    cam.W = (float)W;
+    const float uvx = ((float)x + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
+    uint32_t rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)frame * 719393u;           // :361-362
+    {
+        float lx = (uvx - 0.5f) * p.viewParams[0], ly = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
+        cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * ly) + M[2]  * lz) + M[3]  * 1.0f,
+                                 ((M[4] * lx + M[5] * ly) + M[6]  * lz) + M[7]  * 1.0f,
+                                 ((M[8] * lx + M[9] * ly) + M[10] * lz) + M[11] * 1.0f);
+    }
+    cam.right = rtm::mk(M[0], M[4], M[8]);
+    cam.up    = rtm::mk(M[1], M[5], M[9]);
+    cam.pos   = ld3(p.worldSpaceCameraPos);
+
+    v3 total = rtm::mk(0.f, 0.f, 0.f);
+    v3 o, d;
+    v3 rayColour = rtm::mk(1.f, 1.f, 1.f), light = rtm::mk(0.f, 0.f, 0.f);
+    int sample = 0, bounce = 0;
+    bool alive = p.numRaysPerPixel > 0;
+    if (alive) camera_ray(p, cam, rng, o, d);
+
+    while (alive) {
+        Hit h; v3 nrm_flat; uint32_t chunk_flat;
+        if (FLAT) h = closest_hit_flat(S, p.intersectMode, o, d, nrm_flat, chunk_flat);
+        else      h = closest_hit<COUNT>(S, p.intersectMode, o, d, stk, cnt);
+
+        bool path_done;
+        if (h.id != kNone) {
+            // ---- hit: Trace :309-343
+            const v3 hitPoint = o + d * h.t;
+            v3 normal; const float4* mat;
+            if (h.id & kTriBit) {
+                const uint32_t ti = h.id & ~kTriBit;
+                if (FLAT) {
+                    normal = rtm::normalize(nrm_flat);
+                    mat = S.chunk_mat + (size_t)chunk_flat * 4;
+                } else {
+                    const float4* tn = S.tri_nrm + (size_t)ti * 3;
+                    const float4 n0 = tn[0], n1 = tn[1], n2 = tn[2];
+                    const float w = 1.0f - h.u - h.v;
+                    normal = rtm::normalize((rtm::mk(n0.x, n0.y, n0.z) * w + rtm::mk(n1.x, n1.y, n1.z) * h.u)
+                                            + rtm::mk(n2.x, n2.y, n2.z) * h.v);
+                    mat = S.chunk_mat + (size_t)__float_as_uint(n0.w) * 4;
+                }
+            } else {
+                const float4 s = S.sph_geom[h.id];
+                normal = rtm::normalize(hitPoint - rtm::mk(s.x, s.y, s.z));
+                mat = S.sph_mat + (size_t)h.id * 4;
+            }
+            const float4 mcol = mat[0], memi = mat[1], mspec = mat[2], mprm = mat[3];
+            const int flag = (int)__float_as_uint(mprm.w);
+            v3 colour = rtm::mk(mcol.x, mcol.y, mcol.z);
+            bool skip = false;
+            if (flag == 1) {                                                           // CheckerPattern :313-317
+                float cx = mod2(__builtin_floorf(hitPoint.x)), cz = mod2(__builtin_floorf(hitPoint.z));
+                if (!(cx == cz)) colour = rtm::mk(memi.x, memi.y, memi.z);
+            } else if (flag == 2 && bounce == 0) {                                     // InvisibleLightSource :318-322
+                o = hitPoint + d * 0.001f;
+                skip = true;
+            }
+            path_done = false;
+            if (!skip) {
+                const bool isSpecular = mprm.z >= rtm::random_value(rng);              // :325
+                const float specF = isSpecular ? 1.0f : 0.0f;
+                o = hitPoint;                                                          // :327
+                v3 diffuseDir = rtm::normalize(normal + rtm::random_direction(rng));
+                v3 specularDir = rtm::reflect(d, normal);
+                d = rtm::normalize(rtm::lerp(diffuseDir, specularDir, mprm.y * specF));
+
+                v3 emitted = rtm::mk(memi.x, memi.y, memi.z) * mprm.x;                 // :333-335
+                light = light + emitted * rayColour;
+                rayColour = rayColour * rtm::lerp(colour, rtm::mk(mspec.x, mspec.y, mspec.z), specF);
+
+                float pr = rtm::fmax_(rayColour.x, rtm::fmax_(rayColour.y, rayColour.z));   // :338-342
+                if (rtm::random_value(rng) >= pr) path_done = true;
+                else { float ip = 1.0f / pr; rayColour = rayColour * ip; }
+            }
+            ++bounce;
+            if (bounce > p.maxBounceCount) path_done = true;                           // loop bound :305
+        } else {
+            light = light + environment_light(p, d) * rayColour;                       // :346-347
+            path_done = true;
+        }
+
+        if (path_done) {
+            total = total + light;                                                     // :384
+            ++sample;
+            if (sample >= p.numRaysPerPixel) alive = false;
+            else {
+                camera_ray(p, cam, rng, o, d);
+                bounce = 0;
+                rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
+            }
+        }
+    }
+    const float n = (float)p.numRaysPerPixel;
+    return rtm::mk(total.x / n, total.y / n, total.z / n);                             // :387
+}
+
+constexpr int kBlock = 256;         // 4 waves
+constexpr int kWavesPerBlock = kBlock / 64;
+
+template <bool COUNT, bool FLAT>
+__global__ __launch_bounds__(kBlock) void k_trace(DeviceScene S, FrameArgs F)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stk = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
+    Counters cnt = { 0, 0, 0, 0, 0 };
+    const int ntiles = F.tiles_x * F.tiles_y;
+    const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48
+    const float omw = 1.0f - weight;
+
+    for (;;) {
+        unsigned int tile = 0;
+        if (lane == 0) tile = atomicAdd(F.tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= (unsigned)ntiles) break;
+        const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
+        const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+        if (x < F.p.width && ly < F.nrows) {
+            const int y = F.row0 + ly;
+            v3 c = render_pixel<COUNT, FLAT>(S, F.p, F.frame, x, y, stk, cnt);
+            const size_t pi = (size_t)ly * F.p.width + x;
+            F.out_frame[pi] = make_float4(c.x, c.y, c.z, 1.0f);                        // frag :388
+            float4 prev = F.accum[pi];                                                 // Accumulate.shader:45-50
+            float4 acc;
+            acc.x = rtm::saturate(prev.x * omw + c.x * weight);
+            acc.y = rtm::saturate(prev.y * omw + c.y * weight);
+            acc.z = rtm::saturate(prev.z * omw + c.z * weight);
+            acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
+            F.accum[pi] = acc;
+        }
+    }
+    if (COUNT) {
+        unsigned long long v[5] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
+        for (int k = 0; k < 5; ++k) {
+            unsigned long long s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) atomicAdd(&F.counters[k], s);
+        }
+    }
+}
+
+} // namespace rtk

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rtx():
+    import rtx_pkg
+    return rtx_pkg.load()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_binding
+    return oracle_binding.Oracle()
+
+
+@pytest.fixture(scope="session")
+def tracer(rtx):
+    """One HIP context for the whole GPU session (fails loudly without the built library or a GPU)."""
+    t = rtx.Tracer(0)
+    yield t
+    t.close()
