@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the per-pixel ray-trace path on MI355X.
+
+Metric (BASELINE.json): Mrays/s and ms/frame at 1920x1080, 64 rays/pixel/frame (1024 spp = 16 frames), 8 bounces,
+on the ~100k-triangle scene (configs[2]).  A *step* is one frame = one trace+accumulate pass over the image
+(RayTracingManager.OnRenderImage, RayTracingManager.cs:74-81); a *ray* is one CalculateRayCollision
+(RayTracing.shader:256), counted by the kernel itself.
+
+    python bench.py --gpus 1 --steps 16 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+N > 1: the image is cut into N contiguous row strips (seeds use global pixel coordinates, so the image does not
+depend on the decomposition), every rank traces its strip for all K frames, and one RCCL gather to rank 0 at the end
+collects the accumulated strips (inside the timed region).  Total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+NODE_BYTES, TRI_BYTES, SPHERE_BYTES, HIT_BYTES, PIXEL_BYTES = 128, 48, 16, 64 + 48, 48
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3, help="workload: 2 (12 spheres), 3 (~100k tris, headline), 5 (~1M tris, DOF)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--rays", type=int, default=0, help="override rays per pixel per frame (default 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
+    return ap.parse_args()
+
+
+def build_workload(rtx, args):
+    gen = {2: rtx.scenes.config2, 3: rtx.scenes.config3, 5: rtx.scenes.config5}[args.config]
+    mgr = gen(args.width, args.height) if args.width and args.height else gen()
+    if args.rays:
+        mgr.numRaysPerPixel = args.rays
+    return mgr
+
+
+def cpu_baseline(rtx, buffers):
+    """The oracle (reference algorithm: flat chunk loop) timed on this box's host cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    orc = oracle_binding.Oracle()
+    params, spheres, tris, infos = buffers
+    W, H = int(params["width"]), int(params["height"])
+    n = 64 if len(tris) > 20000 else 128
+    p = params.copy()
+    rays_pp = int(p["numRaysPerPixel"])
+    x0, y0 = (W - n) // 2, (H - n) // 2
+    # calibrate on 1/16 of the sample, then size the sample for ~15 s
+    t0 = time.time()
+    _, c = orc.render_frame(p, spheres, tris, infos, 0, (x0, y0, x0 + n // 4, y0 + n // 4))
+    dt = max(time.time() - t0, 1e-3)
+    est_full = dt * 16
+    if est_full > 30:
+        p["numRaysPerPixel"] = max(1, int(rays_pp * 20 / est_full))
+    t0 = time.time()
+    _, c = orc.render_frame(p, spheres, tris, infos, 0, (x0, y0, x0 + n, y0 + n))
+    dt = time.time() - t0
+    return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": c["threads"], "kind": "port",
+            "sample": f"{n}x{n} centre crop of frame 0, {int(p['numRaysPerPixel'])} rays/pixel, FLAT_CHUNKS "
+                      f"(the reference's chunk loop), {c['rays']} rays in {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    import numpy as np
+    import torch
+    import rtx_pkg
+    rtx = rtx_pkg.load()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mgr = build_workload(rtx, args)
+    buffers = mgr.build_buffers()
+    params, spheres, tris, infos = buffers
+    W, H = int(params["width"]), int(params["height"])
+    rows = (H + world - 1) // world
+    row0 = min(rank * rows, H)
+    nrows = max(0, min(rows, H - row0))
+
+    tr = rtx.Tracer(local_rank)
+    tr.set_params(params)
+    tr.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+    tr.set_rows(row0, nrows)
+    strip = torch.zeros(rows * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+    gathered = [torch.empty_like(strip) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup (untimed): also builds the BVH and uploads
+    tr.render(0, max(args.warmup, 0))
+    if dist is not None:                      # warm the RCCL communicator
+        dist.gather(strip, gathered, dst=0)
+    # ---- timed region: exactly K steps + the frame-end gather
+    tr.reset_accum()
+    barrier()
+    t0 = time.perf_counter()
+    tr.render(0, args.steps)
+    if dist is not None:
+        tr.copy_accum_to_device(strip.data_ptr(), nrows * W * 4)
+        dist.gather(strip, gathered, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    st = tr.stats()
+    rays = torch.tensor([float(st["rays"]), dt, st["totalKernelMs"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        tmax = rays.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        total_rays, wall = rays[0].item(), tmax[1].item()
+    else:
+        total_rays, wall = rays[0].item(), dt
+    kernel_ms_rank0 = st["totalKernelMs"]
+
+    # ---- roofline (rank 0's strip): counting build of the same kernel over the same K frames, untimed
+    roofline = None
+    if not args.no_roofline:
+        tr.reset_accum()
+        tr.render_counting(0, args.steps)
+        sc = tr.stats()
+        px = nrows * W * args.steps
+        alg = (sc["nodeVisits"] * NODE_BYTES + sc["triTests"] * TRI_BYTES + sc["sphereTests"] * SPHERE_BYTES
+               + sc["hits"] * HIT_BYTES + px * PIXEL_BYTES)
+        per_launch = alg / max(args.steps, 1)
+        launch_s = kernel_ms_rank0 / 1e3 / max(args.steps, 1)
+        ach = per_launch / launch_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}"
+                traffic = tj.get(key, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBPS, 5), "traffic": traffic,
+                    "kernel": "k_trace<false,false>", "launch_ms": round(launch_s * 1e3, 3),
+                    "algorithmic_bytes_per_launch": int(per_launch),
+                    "per_ray": {"nodes": round(sc["nodeVisits"] / max(sc["rays"], 1), 2),
+                                "tris": round(sc["triTests"] / max(sc["rays"], 1), 2),
+                                "spheres": round(sc["sphereTests"] / max(sc["rays"], 1), 2)}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(rtx, buffers)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    tr.close()
+    if rank != 0:
+        return
+    names = {2: "configs[1]: 12 spheres Cornell style", 3: "configs[2]: Chess pieces x17 (100,440 triangles, BVH4)",
+             5: "configs[4]: Chess pieces x170 (1,004,364 triangles, BVH4), DOF on"}
+    out = {
+        "metric": "Mrays/s", "value": round(total_rays / wall / 1e6, 2), "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{names[args.config]}, {W}x{H}, {int(params['numRaysPerPixel'])} rays/pixel/frame "
+                               f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, PCG, FLAT_CHUNKS semantics",
+                   "decomposition": f"{world} row strip(s) + one RCCL gather" if world > 1 else "single GPU",
+                   "rays_per_frame": int(total_rays / max(args.steps, 1)),
+                   "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres))},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -99,8 +99,8 @@ typedef struct rt_stats {
     int32_t  numSpheres;
     int32_t  numBvhNodes;
     int32_t  bvhMaxStack;               /* worst-case traversal stack depth of the built BVH             */
-    uint64_t rays;                      /* CalculateRayCollision invocations (counting renders only)     */
-    uint64_t sphereTests;
+    uint64_t rays;                      /* CalculateRayCollision invocations of the last render call     */
+    uint64_t sphereTests;               /* the remaining counters: rt_render_counting only               */
     uint64_t nodeVisits;                /* BVH nodes fetched                                             */
     uint64_t triTests;
     uint64_t hits;                      /* rays that hit something                                       */

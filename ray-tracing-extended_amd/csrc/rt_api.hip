@@ -225,7 +225,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     const int want = (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
     const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
 
-    if (var == Variant::Counting) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 5 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 5 * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < n_frames; ++i) {
         F.frame = first_frame + i;
@@ -243,10 +243,12 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     RT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.lastKernelMs = ms; c->stats.totalKernelMs += ms;
     c->stats.numRenderedFrames += n_frames;
-    if (var == Variant::Counting) {
+    {
         unsigned long long h[5];
         RT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-        c->stats.rays = h[0]; c->stats.sphereTests = h[1]; c->stats.nodeVisits = h[2]; c->stats.triTests = h[3]; c->stats.hits = h[4];
+        c->stats.rays = h[0];                        // counted by every variant
+        if (var == Variant::Counting) { c->stats.sphereTests = h[1]; c->stats.nodeVisits = h[2]; c->stats.triTests = h[3]; c->stats.hits = h[4]; }
+        else { c->stats.sphereTests = c->stats.nodeVisits = c->stats.triTests = c->stats.hits = 0; }
     }
     return 0;
 }

@@ -110,7 +110,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                                            uint32_t* stk, Counters& cnt)
 {
     Hit best; best.t = __builtin_inff(); best.id = kNone; best.u = 0.f; best.v = 0.f;
-    if (COUNT) cnt.rays++;
+    cnt.rays++;                                  // rays are always counted (one add per cast)
 
     // CalculateRayCollision :263-273 — buffer order, strict '<' (first sphere wins ties)
     const float a = rtm::dot(d, d);
@@ -293,7 +293,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
 
     while (alive) {
         Hit h; v3 nrm_flat; uint32_t chunk_flat;
-        if (FLAT) h = closest_hit_flat(S, p.intersectMode, o, d, nrm_flat, chunk_flat);
+        if (FLAT) { h = closest_hit_flat(S, p.intersectMode, o, d, nrm_flat, chunk_flat); cnt.rays++; }
         else      h = closest_hit<COUNT>(S, p.intersectMode, o, d, stk, cnt);
 
         bool path_done;
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(DeviceScene S, FrameArgs F)
             F.accum[pi] = acc;
         }
     }
-    if (COUNT) {
+    {
         unsigned long long v[5] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < (COUNT ? 5 : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0) atomicAdd(&F.counters[k], s);

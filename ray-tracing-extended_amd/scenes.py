@@ -206,3 +206,69 @@ def mesh_test_scene(width: int = 96, height: int = 64, n_objects: int = 6, seed:
     m.spheres.append(_sphere((-2.0, 0.5, -3.5), 1.0, colour=(0.9, 0.3, 0.2, 1), emissionColour=black,
                              specularColour=white, specularProbability=0.0))
     return m
+
+
+# ---- configs[2..4]: the reference's Chess scene, instanced -------------------------------------------------------
+import os as _os
+
+GOLDEN_SCENES = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests", "golden", "scenes")
+
+
+def chess_instanced(copies: int, width: int = 1920, height: int = 1080, columns: int = 5, spacing: float = 9.0,
+                    dof: bool = False, bounces: int = 8, scene_path: str = None) -> RayTracingManager:
+    """The 15 pieces of Assets/Scenes/Chess.unity (5,908 triangles) instanced `copies` times on a grid in front of
+    the camera, copy k > 0 yawed about its own board centre by a PCG-seeded angle (seed 3), over one checker floor
+    quad, lit by the scene's invisible area light and its sky (sunIntensity 0, Chess.unity:30179-30185).
+    copies = 17 -> 100,436 + 4 triangles (configs[2], [3]); copies = 170 -> 1,004,360 + 4 (configs[4])."""
+    from .unity_scene import load_scene_npz
+    base = load_scene_npz(scene_path or _os.path.join(GOLDEN_SCENES, "Chess.npz"), width, height)
+    pieces = [m for m in base.meshes if m.triangleCount > 2]
+    quads = [m for m in base.meshes if m.triangleCount <= 2]
+    board = next(q for q in quads if q.materials[0].flag == MaterialFlag.CheckerPattern)
+    light = next(q for q in quads if q.materials[0].flag == MaterialFlag.InvisibleLight)
+    assert len(pieces) == 15 and sum(p.triangleCount for p in pieces) == 5908
+
+    mgr = RayTracingManager(base.camera, base.light, width, height)
+    mgr.maxBounceCount, mgr.numRaysPerPixel = bounces, 64
+    mgr.environmentSettings = base.environmentSettings
+    mgr.focusDistance = base.focusDistance                       # 3.82 (Chess.unity:30178)
+    if dof:
+        mgr.defocusStrength, mgr.divergeStrength = base.defocusStrength, base.divergeStrength   # 180, 1 (:30176-30177)
+    else:
+        mgr.defocusStrength, mgr.divergeStrength = 0.0, base.divergeStrength
+
+    rng = Pcg(3)
+    rows = (copies + columns - 1) // columns
+    from .host import quat_mul, quat_rotate
+    for k in range(copies):
+        gx, gz = k % columns - columns // 2, k // columns
+        # copy 0 sits where the reference scene is; the grid grows to both sides and away from the camera
+        off = np.array([gx * spacing, 0.0, gz * spacing], np.float32)
+        yaw = 0.0 if k == 0 else rng.value() * 2.0 * np.pi
+        qy = np.array([0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)], np.float32)
+        for p in pieces:
+            tr = Transform(position=(quat_rotate(qy, p.transform.position) + off).astype(np.float32),
+                           rotation=quat_mul(qy, p.transform.rotation), lossyScale=p.transform.lossyScale)
+            mgr.meshes.append(RayTracedMesh(tr, p.materials, p.localChunks, triangleCount=p.triangleCount))
+    # one floor under the whole grid (the board quad is the unit quad [-0.5,0.5]^2 scaled by 8 in the reference)
+    span_x, span_z = columns * spacing + 8.0, rows * spacing + 8.0
+    s = float(max(span_x, span_z))
+    mgr.meshes.append(RayTracedMesh(Transform(position=(0.0, 0.0, (rows - 1) * spacing * 0.5), rotation=board.transform.rotation,
+                                              lossyScale=(s, s, s)), board.materials, board.localChunks, triangleCount=2))
+    mgr.meshes.append(RayTracedMesh(light.transform, light.materials, light.localChunks, triangleCount=2))
+    return mgr
+
+
+def config3(width: int = 1920, height: int = 1080) -> RayTracingManager:
+    """configs[2]: ~100k triangles, 1920x1080, 1024 spp = 16 frames x 64 rays, 8 bounces, DOF off."""
+    return chess_instanced(17, width, height, bounces=8)
+
+
+def config4(width: int = 3840, height: int = 2160) -> RayTracingManager:
+    """configs[3]: same scene, 3840x2160, 4096 spp = 64 frames x 64 rays, 12 bounces (8 GPUs, row strips)."""
+    return chess_instanced(17, width, height, bounces=12)
+
+
+def config5(width: int = 1920, height: int = 1080) -> RayTracingManager:
+    """configs[4]: ~1.0M triangles (170 copies, 17 columns), DOF on (180 / 1 / 3.82), 1024 spp, 8 bounces."""
+    return chess_instanced(170, width, height, columns=17, bounces=8, dof=True)
