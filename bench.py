@@ -58,17 +58,19 @@ def cpu_baseline(rtx, buffers):
     orc = oracle_binding.Oracle()
     params, spheres, tris, infos = buffers
     W, H = int(params["width"]), int(params["height"])
-    n = 64 if len(tris) > 20000 else 128
     p = params.copy()
     rays_pp = int(p["numRaysPerPixel"])
-    x0, y0 = (W - n) // 2, (H - n) // 2
-    # calibrate on 1/16 of the sample, then size the sample for ~15 s
+    # calibrate on a 16x16 window, then size the sample (crop side, then rays/pixel) for ~15 s of wall time
     t0 = time.time()
-    _, c = orc.render_frame(p, spheres, tris, infos, 0, (x0, y0, x0 + n // 4, y0 + n // 4))
-    dt = max(time.time() - t0, 1e-3)
-    est_full = dt * 16
-    if est_full > 30:
-        p["numRaysPerPixel"] = max(1, int(rays_pp * 20 / est_full))
+    orc.render_frame(p, spheres, tris, infos, 0, ((W - 16) // 2, (H - 16) // 2, (W + 16) // 2, (H + 16) // 2))
+    per_px = max(time.time() - t0, 1e-3) / 256
+    n = 64
+    while n < 512 and per_px * (2 * n) ** 2 < 15:
+        n *= 2
+    n = min(n, W, H)
+    if per_px * n * n > 30:
+        p["numRaysPerPixel"] = max(1, int(rays_pp * 20 / (per_px * n * n)))
+    x0, y0 = (W - n) // 2, (H - n) // 2
     t0 = time.time()
     _, c = orc.render_frame(p, spheres, tris, infos, 0, (x0, y0, x0 + n, y0 + n))
     dt = time.time() - t0
