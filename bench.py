@@ -102,16 +102,13 @@ def main():
     buffers = mgr.build_buffers()
     params, spheres, tris, infos = buffers
     W, H = int(params["width"]), int(params["height"])
-    rows = (H + world - 1) // world
-    row0 = min(rank * rows, H)
-    nrows = max(0, min(rows, H - row0))
+    row0, nrows, rows = rtx.distributed.row_strip(H, world, rank)
 
     tr = rtx.Tracer(local_rank)
     tr.set_params(params)
     tr.upload(spheres=spheres, triangles=tris, meshinfo=infos)
     tr.set_rows(row0, nrows)
-    strip = torch.zeros(rows * W * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
-    gathered = [torch.empty_like(strip) for _ in range(world)] if (world > 1 and rank == 0) else None
+    strip = torch.zeros(rows, W, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def barrier():
         if dist is not None:
@@ -121,7 +118,7 @@ def main():
     # ---- warmup (untimed): also builds the BVH and uploads
     tr.render(0, max(args.warmup, 0))
     if dist is not None:                      # warm the RCCL communicator
-        dist.gather(strip, gathered, dst=0)
+        rtx.distributed.gather_image(strip, H, dist)
     # ---- timed region: exactly K steps + the frame-end gather
     tr.reset_accum()
     barrier()
@@ -129,7 +126,7 @@ def main():
     tr.render(0, args.steps)
     if dist is not None:
         tr.copy_accum_to_device(strip.data_ptr(), nrows * W * 4)
-        dist.gather(strip, gathered, dst=0)
+        image = rtx.distributed.gather_image(strip, H, dist)      # [H, W, 4] on rank 0
     barrier()
     dt = time.perf_counter() - t0
     st = tr.stats()

@@ -1,0 +1,35 @@
+"""Row-strip image decomposition across the GPUs of one node + the single frame-end gather (RCCL over xGMI; the same
+code runs on gloo for CPU tests).
+
+The path shards into independent units: a pixel depends only on (x, y, W, H, frame, scene) — seeds use global pixel
+coordinates (RayTracing.shader:360-362) and accumulation is per pixel (Accumulate.shader:43-54) — so each rank traces
+rows [row0, row0+nrows) for all frames with no data-path exchange, and one gather to rank 0 collects the strips.
+A gather on a fully connected xGMI node is N-1 independent point-to-point transfers into the root.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+
+def row_strip(height: int, world: int, rank: int) -> Tuple[int, int, int]:
+    """-> (row0, nrows, rows_per_rank).  Contiguous strips of ceil(H/world) rows; trailing ranks may get fewer (or
+    zero) rows; rows_per_rank is the padded strip height every rank contributes to the gather."""
+    if world < 1 or not (0 <= rank < world) or height < 0:
+        raise ValueError(f"bad decomposition: height={height} world={world} rank={rank}")
+    per = (height + world - 1) // world
+    row0 = min(rank * per, height)
+    return row0, max(0, min(per, height - row0)), per
+
+
+def gather_image(strip, height: int, dist=None, dst: int = 0):
+    """strip: torch tensor [rows_per_rank, W, 4] (rows beyond this rank's nrows are padding).  Returns the assembled
+    [height, W, 4] image on rank `dst`, None elsewhere.  One collective."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return strip[:height]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bufs = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
+    dist.gather(strip, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat(bufs, dim=0)[:height]

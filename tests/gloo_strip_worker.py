@@ -1,0 +1,23 @@
+"""Worker of test_two_rank_gloo_strips_assemble_to_the_full_image (launched by torch.distributed.run, gloo)."""
+import os, sys
+sys.path.insert(0, os.environ["RTX_ROOT"]); sys.path.insert(0, os.path.join(os.environ["RTX_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import rtx_pkg, oracle_binding
+rtx = rtx_pkg.load(); orc = oracle_binding.Oracle()
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+b = rtx.scenes.mesh_test_scene(40, 27).build_buffers()      # 27 rows: uneven split (14 + 13)
+H, W = 27, 40
+row0, nrows, per = rtx.distributed.row_strip(H, world, rank)
+acc, _, _ = orc.render(*b, 0, 2, rect=(0, row0, W, row0 + nrows))
+strip = torch.zeros(per, W, 4)
+strip[:nrows] = torch.from_numpy(acc)
+img = rtx.distributed.gather_image(strip, H, dist)
+if rank == 0:
+    full, _, _ = orc.render(*b, 0, 2)
+    assert img.shape == (H, W, 4)
+    assert np.array_equal(img.numpy().view(np.uint32), full.view(np.uint32)), "assembled image differs"
+    print("GLOO_OK")
+else:
+    assert img is None
+dist.destroy_process_group()
