@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--rays", type=int, default=0, help="override rays per pixel per frame (default 64)")
+    ap.add_argument("--kernel", type=int, default=-1, help="tuning: 0 tile-per-wave megakernel, 1 streaming megakernel (library default)")
+    ap.add_argument("--shade-threshold", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
     return ap.parse_args()
@@ -108,6 +111,12 @@ def main():
     tr.set_params(params)
     tr.upload(spheres=spheres, triangles=tris, meshinfo=infos)
     tr.set_rows(row0, nrows)
+    if args.kernel >= 0:
+        tr.set_option("kernel", args.kernel)
+    if args.shade_threshold:
+        tr.set_option("shade_threshold", args.shade_threshold)
+    if args.blocks_per_cu:
+        tr.set_option("blocks_per_cu", args.blocks_per_cu)
     strip = torch.zeros(rows, W, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def barrier():
@@ -167,7 +176,12 @@ def main():
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "per_ray": {"nodes": round(sc["nodeVisits"] / max(sc["rays"], 1), 2),
                                 "tris": round(sc["triTests"] / max(sc["rays"], 1), 2),
-                                "spheres": round(sc["sphereTests"] / max(sc["rays"], 1), 2)}}
+                                "spheres": round(sc["sphereTests"] / max(sc["rays"], 1), 2)},
+                    "phase_lane_utilisation": {n: round(l / max(64 * e, 1), 3) for n, l, e in
+                                               zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseLanes"], sc["phaseExecs"])},
+                    "phase_wave_execs_per_ray": {n: round(e * 64 / max(sc["rays"], 1), 2) for n, e in
+                                                 zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseExecs"])},
+                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(rtx, buffers)

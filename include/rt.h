@@ -104,6 +104,9 @@ typedef struct rt_stats {
     uint64_t nodeVisits;                /* BVH nodes fetched                                             */
     uint64_t triTests;
     uint64_t hits;                      /* rays that hit something                                       */
+    uint64_t phaseLanes[5];             /* active lanes summed over executions of phase k: 0 BVH node step,  */
+    uint64_t phaseExecs[5];             /* 1 triangle test, 2 hit shading, 3 environment, 4 camera ray;      */
+                                        /* lane utilisation of phase k = phaseLanes[k] / (64*phaseExecs[k])  */
     double   lastKernelMs;              /* HIP-event time of the last trace(+accumulate) launch          */
     double   totalKernelMs;             /* sum over launches since rt_reset_accum                        */
 } rt_stats;
@@ -132,6 +135,11 @@ int rt_set_params(rt_ctx* ctx, const rt_params* params);
 int rt_upload_spheres  (rt_ctx* ctx, const rt_sphere*   spheres,  int n);
 int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris,     int n);
 int rt_upload_meshinfo (rt_ctx* ctx, const rt_meshinfo* meshinfo, int n);
+
+/* Tuning knobs; results never depend on them.  "kernel": 1 = phase-scheduled streaming megakernel (default),
+ * 0 = tile-per-wave megakernel; "shade_threshold": lanes (1..64) that must wait for shading before the wave leaves
+ * traversal; "blocks_per_cu": cap on resident workgroups per CU (0 = occupancy query).                          */
+int rt_set_option(rt_ctx* ctx, const char* name, int value);
 
 /* Row strip rendered by this context: rows [row0, row0+nrows) of the full width x height image.
  * Seeds use global pixel coordinates (RayTracing.shader:360-362) so the image is decomposition-invariant.

@@ -38,6 +38,7 @@ STATS = np.dtype([
     ("numRenderedFrames", "<i4"), ("numMeshChunks", "<i4"), ("numTriangles", "<i4"), ("numSpheres", "<i4"),
     ("numBvhNodes", "<i4"), ("bvhMaxStack", "<i4"),
     ("rays", "<u8"), ("sphereTests", "<u8"), ("nodeVisits", "<u8"), ("triTests", "<u8"), ("hits", "<u8"),
+    ("phaseLanes", "<u8", 5), ("phaseExecs", "<u8", 5),
     ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"),
 ])
 assert MATERIAL.itemsize == 64 and SPHERE.itemsize == 80 and TRIANGLE.itemsize == 72 and MESHINFO.itemsize == 96
@@ -50,7 +51,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_params", "rt_upload_spheres",
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
-    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof",
+    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option",
 ]
 
 _lib = None
@@ -80,6 +81,7 @@ def load_library() -> ctypes.CDLL:
     for n in ("rt_upload_spheres", "rt_upload_triangles", "rt_upload_meshinfo"):
         getattr(lib, n).argtypes = [c_void_p, c_void_p, c_int]
     lib.rt_set_rows.argtypes = [c_void_p, c_int, c_int]
+    lib.rt_set_option.argtypes = [c_void_p, c_char_p, c_int]
     lib.rt_render_frame.argtypes = [c_void_p, c_int]
     lib.rt_render_frame_flat.argtypes = [c_void_p, c_int]
     lib.rt_render.argtypes = [c_void_p, c_int, c_int]
@@ -162,6 +164,9 @@ class Tracer:
         self._rows = (row0, nrows)
         self._check(self._lib.rt_set_rows(self._ctx, row0, nrows), "rt_set_rows")
 
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.rt_set_option(self._ctx, name.encode(), int(value)), f"rt_set_option({name})")
+
     def set_stream(self, stream_ptr):
         self._check(self._lib.rt_set_stream(self._ctx, c_void_p(stream_ptr)), "rt_set_stream")
 
@@ -205,4 +210,4 @@ class Tracer:
     def stats(self) -> dict:
         s = np.zeros((), STATS)
         self._check(self._lib.rt_get_stats(self._ctx, s.ctypes.data_as(c_void_p)), "rt_get_stats")
-        return {k: s[k].item() for k in STATS.names}
+        return {k: (s[k].item() if s[k].ndim == 0 else s[k].tolist()) for k in STATS.names}

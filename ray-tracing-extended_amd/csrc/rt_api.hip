@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "rt_kernels.hpp"
+#include "rt_stream.hpp"
 
 namespace {
 
@@ -65,6 +66,9 @@ struct rt_ctx {
 
     rtbvh::Bvh bvh;
     int n_cu = 0;
+    int opt_kernel = 1;             // 0: k_trace (tile-per-wave), 1: k_stream (phase-scheduled, streaming pixels)
+    int opt_shade_threshold = 24;
+    int opt_blocks_per_cu = 0;      // 0: occupancy API
     rt_stats stats{};
 };
 
@@ -208,32 +212,40 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     F.p = c->params;
     F.row0 = c->target_row0; F.nrows = c->target_rows;
     F.tiles_x = (c->target_w + 7) / 8; F.tiles_y = (c->target_rows + 7) / 8;
-    F.stack_cap = std::max(1, c->bvh.maxStack);
+    const bool stream = c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
+    F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // k_stream's branch-free push writes up to 3 slots past the top
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
     F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
 
     const size_t lds = var == Variant::Flat ? 0 : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
     if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
-    const void* fn = var == Variant::Fast ? (const void*)rtk::k_trace<false, false>
-                   : var == Variant::Counting ? (const void*)rtk::k_trace<true, false>
-                                              : (const void*)rtk::k_trace<false, true>;
+    const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
+                   : stream ? (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>)
+                            : (var == Variant::Fast ? (const void*)rtk::k_trace<false, false> : (const void*)rtk::k_trace<true, false>);
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::kBlock, lds));
     if (per_cu < 1) return fail(c, -7, "kernel does not fit a CU (LDS %zu B)", lds);
     const int ntiles = F.tiles_x * F.tiles_y;
     const int want = (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
+    if (c->opt_blocks_per_cu > 0) per_cu = std::min(per_cu, c->opt_blocks_per_cu);
     const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
+    rtk::StreamArgs A{};
+    A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
+    A.total_pixels = (unsigned int)ntiles * 64u;
 
-    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 5 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < n_frames; ++i) {
         F.frame = first_frame + i;
         RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
-        switch (var) {
-        case Variant::Fast:     hipLaunchKernelGGL((rtk::k_trace<false, false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F); break;
-        case Variant::Counting: hipLaunchKernelGGL((rtk::k_trace<true, false>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F); break;
-        case Variant::Flat:     hipLaunchKernelGGL((rtk::k_trace<false, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F); break;
+        if (var == Variant::Flat) hipLaunchKernelGGL((rtk::k_trace<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
+        else if (stream) {
+            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+            else                      hipLaunchKernelGGL((rtk::k_stream<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+        } else {
+            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_trace<false, false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
+            else                      hipLaunchKernelGGL((rtk::k_trace<true, false>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
         }
         RT_HIP(c, hipGetLastError());
     }
@@ -244,11 +256,16 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     c->stats.lastKernelMs = ms; c->stats.totalKernelMs += ms;
     c->stats.numRenderedFrames += n_frames;
     {
-        unsigned long long h[5];
+        unsigned long long h[rtk::kNumCounters];
         RT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
         c->stats.rays = h[0];                        // counted by every variant
-        if (var == Variant::Counting) { c->stats.sphereTests = h[1]; c->stats.nodeVisits = h[2]; c->stats.triTests = h[3]; c->stats.hits = h[4]; }
-        else { c->stats.sphereTests = c->stats.nodeVisits = c->stats.triTests = c->stats.hits = 0; }
+        if (var == Variant::Counting) {
+            c->stats.sphereTests = h[1]; c->stats.nodeVisits = h[2]; c->stats.triTests = h[3]; c->stats.hits = h[4];
+            for (int k = 0; k < 5; ++k) { c->stats.phaseLanes[k] = h[5 + k]; c->stats.phaseExecs[k] = h[10 + k]; }
+        } else {
+            c->stats.sphereTests = c->stats.nodeVisits = c->stats.triTests = c->stats.hits = 0;
+            for (int k = 0; k < 5; ++k) c->stats.phaseLanes[k] = c->stats.phaseExecs[k] = 0;
+        }
     }
     return 0;
 }
@@ -303,7 +320,7 @@ rt_ctx* rt_create(int device)
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess
         || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess
         || (e = hipMalloc((void**)&c->d_tile_counter, sizeof(unsigned int))) != hipSuccess
-        || (e = hipMalloc((void**)&c->d_counters, 5 * sizeof(unsigned long long))) != hipSuccess) {
+        || (e = hipMalloc((void**)&c->d_counters, rtk::kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
         fail(nullptr, -1, "context setup: %s", hipGetErrorString(e));
         rt_destroy(c);
         return nullptr;
@@ -366,6 +383,17 @@ int rt_upload_meshinfo(rt_ctx* c, const rt_meshinfo* m, int n)
     if (!c) return -1;
     if (n < 0 || (n > 0 && !m)) return fail(c, -2, "bad meshinfo upload (n=%d)", n);
     c->h_mesh.assign(m, m + n); c->scene_dirty = true;
+    return 0;
+}
+
+int rt_set_option(rt_ctx* c, const char* name, int value)
+{
+    if (!c) return -1;
+    if (!name) return fail(c, -2, "null option name");
+    if (!std::strcmp(name, "kernel")) { if (value != 0 && value != 1) return fail(c, -2, "kernel must be 0 or 1"); c->opt_kernel = value; }
+    else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
+    else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }
+    else return fail(c, -2, "unknown option '%s'", name);
     return 0;
 }
 

@@ -47,7 +47,7 @@ struct FrameArgs {
     float4* out_frame;          // [nrows*W] currentFrame
     float4* accum;              // [nrows*W] resultTexture
     unsigned int* tile_counter;
-    unsigned long long* counters;   // [5] rays, sphereTests, nodeVisits, triTests, hits
+    unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5]
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -59,7 +59,20 @@ struct Hit {
     float    u, v;    // barycentrics of the winning triangle
 };
 
-struct Counters { uint32_t rays, sph, nodes, tris, hits; };
+// Work counters (rays always; the rest in the counting build).  phase_lanes[k] / (64 * phase_execs[k]) is the lane
+// utilisation of phase k (0 node step, 1 triangle test, 2 hit shading, 3 environment, 4 camera ray).
+struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; };
+constexpr int kNumCounters = 15;
+
+template <bool COUNT>
+__device__ __forceinline__ void phase_tick(Counters& cnt, int k)
+{
+    if (COUNT) {
+        cnt.phase_lanes[k]++;
+        const unsigned long long m = __ballot(1);
+        if ((unsigned)(__builtin_ctzll(m)) == (threadIdx.x & 63u)) cnt.phase_execs[k]++;
+    }
+}
 
 __device__ __forceinline__ v3 ld3(const float* p) { return rtm::mk(p[0], p[1], p[2]); }
 
@@ -129,6 +142,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
             // ---- descend internal nodes until this lane holds a leaf (or ran dry)
             while ((int)cur >= 0) {
                 if (COUNT) cnt.nodes++;
+                phase_tick<COUNT>(cnt, 0);
                 const float4* nb = S.nodes + (size_t)cur * 8;
                 const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
                 const uint4 ch = *reinterpret_cast<const uint4*>(nb + 6);
@@ -170,6 +184,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                     const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
                     float dst, u, v;
                     if (COUNT) cnt.tris++;
+                    phase_tick<COUNT>(cnt, 1);
                     bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
                                             rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
                     if (hit && dst <= best.t) {
@@ -299,6 +314,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
         bool path_done;
         if (h.id != kNone) {
             // ---- hit: Trace :309-343
+            phase_tick<COUNT>(cnt, 2);
             const v3 hitPoint = o + d * h.t;
             v3 normal; const float4* mat;
             if (h.id & kTriBit) {
@@ -350,6 +366,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
             ++bounce;
             if (bounce > p.maxBounceCount) path_done = true;                           // loop bound :305
         } else {
+            phase_tick<COUNT>(cnt, 3);
             light = light + environment_light(p, d) * rayColour;                       // :346-347
             path_done = true;
         }
@@ -359,6 +376,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
             ++sample;
             if (sample >= p.numRaysPerPixel) alive = false;
             else {
+                phase_tick<COUNT>(cnt, 4);
                 camera_ray(p, cam, rng, o, d);
                 bounce = 0;
                 rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DeviceScene S, FrameArgs F)
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
-    Counters cnt = { 0, 0, 0, 0, 0 };
+    Counters cnt = {};
     const int ntiles = F.tiles_x * F.tiles_y;
     const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48
     const float omw = 1.0f - weight;
@@ -405,8 +423,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(DeviceScene S, FrameArgs F)
         }
     }
     {
-        unsigned long long v[5] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
-        for (int k = 0; k < (COUNT ? 5 : 1); ++k) {
+        unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
+        for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
+        for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0) atomicAdd(&F.counters[k], s);

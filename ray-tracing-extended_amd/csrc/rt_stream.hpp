@@ -1,0 +1,290 @@
+// rt_stream.hpp — the streaming megakernel: same per-pixel arithmetic as k_trace (rt_kernels.hpp), different
+// wave-level schedule.
+//
+// k_trace runs, per loop iteration, one complete closest-hit query for all 64 lanes and then shades all of them:
+// the wave pays for the longest traversal in it (measured on the 100k-triangle workload: 24 node steps executed
+// per 9 needed, lane utilisation 37 % in node steps and 29 % in triangle tests).  Here traversal is *resumable*
+// and the wave picks, step by step, the phase most of its lanes are waiting for:
+//
+//     NODE   one BVH4 node step for the lanes whose current reference is an internal node
+//     TRI    one RayTriangle test for the lanes whose current reference is a leaf
+//     SHADE  for the lanes whose query is complete: hit/miss shading, next bounce or next sample or next pixel,
+//            new ray, sphere loop, traversal reset
+//
+// SHADE runs when at least `shade_threshold` lanes wait for it (or nothing else can run); otherwise NODE or TRI,
+// whichever has more lanes.  Lanes not in the chosen phase keep their state in registers and simply sit out the
+// step.  A lane that finishes its pixel (all NumRaysPerPixel samples) writes it (frame + fused accumulate) and
+// pulls the next pixel index from a global counter (tile-major order, 8x8 tiles), so there is no per-tile tail.
+//
+// Nothing about a pixel's own sequence of operations changes (same RNG chain, same closest-hit arithmetic, same
+// tie-break), so the image is bit-identical to k_trace and to the oracle.
+#pragma once
+#include "rt_kernels.hpp"
+
+namespace rtk {
+
+struct StreamArgs {
+    int shade_threshold;        // lanes waiting for SHADE that trigger it
+    unsigned int total_pixels;  // tiles_x * tiles_y * 64 (tile-major enumeration, padded)
+};
+
+enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2 };
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stk = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
+    Counters cnt = {};
+    const rt_params& p = F.p;
+    const float* M = p.camLocalToWorld;
+    const uint32_t W = (uint32_t)p.width;
+    const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48
+    const float omw = 1.0f - weight;
+    const float INF = __builtin_inff();
+
+    Camera cam;
+    cam.W = (float)W;
+    cam.right = rtm::mk(M[0], M[4], M[8]);
+    cam.up    = rtm::mk(M[1], M[5], M[9]);
+    cam.pos   = ld3(p.worldSpaceCameraPos);
+    cam.focusPoint = rtm::mk(0.f, 0.f, 0.f);
+
+    // ---- per-lane state -------------------------------------------------------------------------------------
+    uint32_t mode = kModeShade;         // every lane starts by asking for a pixel
+    int px = -1, ly = 0;                // current pixel (px < 0: none)
+    uint32_t rng = 0;
+    int sample = 0, bounce = 0;
+    v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total, inv = total;
+    uint32_t cur = kNone; int sp = 0;
+    Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
+    bool live = false;                  // a finished closest-hit query is waiting to be shaded
+
+    for (;;) {
+        const bool isTrav = mode == kModeTrav;
+        const unsigned long long mNode = __ballot(isTrav && (int)cur >= 0);
+        const unsigned long long mLeaf = __ballot(isTrav && (int)cur < 0);
+        const unsigned long long mShade = __ballot(mode == kModeShade);
+        const int nNode = __popcll(mNode), nLeaf = __popcll(mLeaf), nShade = __popcll(mShade);
+        if (nNode + nLeaf + nShade == 0) break;                                       // every lane is dead
+
+        if (nShade >= A.shade_threshold || nNode + nLeaf == 0) {
+            // ================================ SHADE ================================
+            if (mode == kModeShade) {
+                bool need_ray = false;                  // a camera ray must be generated
+                bool path_done = false;
+                if (live) {
+                    if (best.id != kNone) {
+                        // ---- hit: Trace :309-343
+                        phase_tick<COUNT>(cnt, 2);
+                        if (COUNT) cnt.hits++;
+                        const v3 hitPoint = o + d * best.t;
+                        v3 normal; const float4* mat;
+                        if (best.id & kTriBit) {
+                            const uint32_t ti = best.id & ~kTriBit;
+                            const float4* tn = S.tri_nrm + (size_t)ti * 3;
+                            const float4 n0 = tn[0], n1 = tn[1], n2 = tn[2];
+                            const float w = 1.0f - best.u - best.v;
+                            normal = rtm::normalize((rtm::mk(n0.x, n0.y, n0.z) * w + rtm::mk(n1.x, n1.y, n1.z) * best.u)
+                                                    + rtm::mk(n2.x, n2.y, n2.z) * best.v);
+                            mat = S.chunk_mat + (size_t)__float_as_uint(n0.w) * 4;
+                        } else {
+                            const float4 s = S.sph_geom[best.id];
+                            normal = rtm::normalize(hitPoint - rtm::mk(s.x, s.y, s.z));
+                            mat = S.sph_mat + (size_t)best.id * 4;
+                        }
+                        const float4 mcol = mat[0], memi = mat[1], mspec = mat[2], mprm = mat[3];
+                        const int flag = (int)__float_as_uint(mprm.w);
+                        v3 colour = rtm::mk(mcol.x, mcol.y, mcol.z);
+                        bool skip = false;
+                        if (flag == 1) {                                               // CheckerPattern :313-317
+                            float cx = mod2(__builtin_floorf(hitPoint.x)), cz = mod2(__builtin_floorf(hitPoint.z));
+                            if (!(cx == cz)) colour = rtm::mk(memi.x, memi.y, memi.z);
+                        } else if (flag == 2 && bounce == 0) {                         // InvisibleLightSource :318-322
+                            o = hitPoint + d * 0.001f;
+                            skip = true;
+                        }
+                        if (!skip) {
+                            const bool isSpecular = mprm.z >= rtm::random_value(rng);  // :325
+                            const float specF = isSpecular ? 1.0f : 0.0f;
+                            o = hitPoint;                                              // :327
+                            v3 diffuseDir = rtm::normalize(normal + rtm::random_direction(rng));
+                            v3 specularDir = rtm::reflect(d, normal);
+                            d = rtm::normalize(rtm::lerp(diffuseDir, specularDir, mprm.y * specF));
+                            v3 emitted = rtm::mk(memi.x, memi.y, memi.z) * mprm.x;     // :333-335
+                            light = light + emitted * rayColour;
+                            rayColour = rayColour * rtm::lerp(colour, rtm::mk(mspec.x, mspec.y, mspec.z), specF);
+                            float pr = rtm::fmax_(rayColour.x, rtm::fmax_(rayColour.y, rayColour.z));   // :338-342
+                            if (rtm::random_value(rng) >= pr) path_done = true;
+                            else { float ip = 1.0f / pr; rayColour = rayColour * ip; }
+                        }
+                        ++bounce;
+                        if (bounce > p.maxBounceCount) path_done = true;               // loop bound :305
+                    } else {
+                        phase_tick<COUNT>(cnt, 3);
+                        light = light + environment_light(p, d) * rayColour;           // :346-347
+                        path_done = true;
+                    }
+                    if (path_done) {
+                        total = total + light;                                         // :384
+                        ++sample;
+                        if (sample >= p.numRaysPerPixel) {
+                            // ---- pixel complete: frag :387-388 + Accumulate.shader:45-50
+                            const float n = (float)p.numRaysPerPixel;
+                            const float cx = total.x / n, cy = total.y / n, cz = total.z / n;
+                            const size_t pi = (size_t)ly * W + (uint32_t)px;
+                            F.out_frame[pi] = make_float4(cx, cy, cz, 1.0f);
+                            const float4 prev = F.accum[pi];
+                            float4 acc;
+                            acc.x = rtm::saturate(prev.x * omw + cx * weight);
+                            acc.y = rtm::saturate(prev.y * omw + cy * weight);
+                            acc.z = rtm::saturate(prev.z * omw + cz * weight);
+                            acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
+                            F.accum[pi] = acc;
+                            px = -1;
+                        } else need_ray = true;
+                    }
+                    live = false;
+                }
+                // ---- pixel refill: tile-major global order; indices outside the strip are skipped
+                while (true) {
+                    const unsigned long long need = __ballot(px < 0 && mode != kModeDead);
+                    if (need == 0) break;
+                    if (px < 0 && mode != kModeDead) {
+                        unsigned int base = 0;
+                        const int first = __builtin_ctzll(need);
+                        if (lane == first) base = atomicAdd(F.tile_counter, (unsigned int)__popcll(need));
+                        base = __shfl(base, first, 64);
+                        const unsigned int idx = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+                        if (idx >= A.total_pixels) mode = kModeDead;
+                        else {
+                            const unsigned int tile = idx >> 6, within = idx & 63u;
+                            const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (int)(within & 7u);
+                            const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (int)(within >> 3);
+                            if (x < p.width && yy < F.nrows) {
+                                px = x; ly = yy;
+                                const int y = F.row0 + yy;
+                                rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;      // :361-362
+                                total = rtm::mk(0.f, 0.f, 0.f);
+                                sample = 0;
+                                need_ray = true;        // (numRaysPerPixel < 1 is routed to k_trace by the host)
+                            }
+                        }
+                    }
+                }
+                if (mode != kModeDead) {
+                    if (need_ray) {
+                        // ---- frag :364-382
+                        phase_tick<COUNT>(cnt, 4);
+                        const int y = F.row0 + ly;
+                        const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
+                        const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
+                        cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,
+                                                 ((M[4] * lx + M[5] * lyv) + M[6]  * lz) + M[7]  * 1.0f,
+                                                 ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f);
+                        camera_ray(p, cam, rng, o, d);
+                        bounce = 0;
+                        rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
+                    }
+                    {
+                        // ---- new closest-hit query: CalculateRayCollision :256-273 (spheres in buffer order)
+                        cnt.rays++;
+                        best.t = INF; best.id = kNone;
+                        const float a = rtm::dot(d, d);
+                        for (int i = 0; i < S.ns; ++i) {
+                            const float4 s = S.sph_geom[i];
+                            float dst;
+                            if (COUNT) cnt.sph++;
+                            if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+                        }
+                        live = true;
+                        if (S.nn > 0) {
+                            inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // RayBoundingBox :179
+                            cur = 0; sp = 0; mode = kModeTrav;
+                        }
+                    }
+                }
+            }
+        } else if (nNode >= nLeaf) {
+            // ================================ NODE =================================
+            if (isTrav && (int)cur >= 0) {
+                if (COUNT) cnt.nodes++;
+                phase_tick<COUNT>(cnt, 0);
+                const float4* nb = S.nodes + (size_t)cur * 8;
+                const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
+                const uint4 ch = *reinterpret_cast<const uint4*>(nb + 6);
+                float t0, t1, t2, t3;
+                uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define RT_SLAB(K, TK, CK)                                                                                   \
+                {                                                                                            \
+                    float ax = (mnx.K - o.x) * inv.x, bx = (mxx.K - o.x) * inv.x;                            \
+                    float ay = (mny.K - o.y) * inv.y, by = (mxy.K - o.y) * inv.y;                            \
+                    float az = (mnz.K - o.z) * inv.z, bz = (mxz.K - o.z) * inv.z;                            \
+                    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), \
+                                               __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));             \
+                    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), \
+                                               __builtin_fminf(__builtin_fmaxf(az, bz), best.t));           \
+                    TK = (tn <= tf && CK != kNone) ? tn : INF;                                               \
+                }
+                RT_SLAB(x, t0, c0) RT_SLAB(y, t1, c1) RT_SLAB(z, t2, c2) RT_SLAB(w, t3, c3)
+#undef RT_SLAB
+#define RT_CSWAP(TA, CA, TB, CB) { bool s_ = TB < TA; float tt_ = s_ ? TB : TA; float tu_ = s_ ? TA : TB;         \
+                                   uint32_t ct_ = s_ ? CB : CA; uint32_t cu_ = s_ ? CA : CB; TA = tt_; TB = tu_; CA = ct_; CB = cu_; }
+                RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
+                RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2)
+#undef RT_CSWAP
+                // branch-free push of the three farther children (far -> near); slots past the new top are garbage
+                stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
+                stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
+                stk[sp * 64] = c1; sp += (t1 < INF) ? 1 : 0;
+                if (t0 < INF) cur = c0;
+                else if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                else { cur = kNone; mode = kModeShade; }
+            }
+        } else {
+            // ================================ TRI ==================================
+            if (isTrav && (int)cur < 0) {
+                const uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
+                const float4* tg = S.tri_geo + (size_t)ti * 3;
+                const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                float dst, u, v;
+                if (COUNT) cnt.tris++;
+                phase_tick<COUNT>(cnt, 1);
+                const bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
+                                              rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
+                if (hit && dst <= best.t) {
+                    bool take = dst < best.t;
+                    if (!take && (best.id & kTriBit) && best.id != kNone) {
+                        // equal dst: the reference keeps the triangle that comes first in the buffer
+                        uint32_t oc = __float_as_uint(S.tri_nrm[(size_t)ti * 3 + 1].w);
+                        uint32_t ob = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3 + 1].w);
+                        take = oc < ob;
+                    }
+                    if (take && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
+                        // the reference only reaches this triangle if its chunk's box test passes (:279)
+                        uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
+                        float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
+                        take = ray_bounding_box(o, inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
+                    }
+                    if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
+                }
+                // next triangle of the leaf (reference = kLeafBit | first << 2 | count-1), or pop
+                if (cur & 3u) cur += 3u;            // first + 1, count - 1
+                else if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                else { cur = kNone; mode = kModeShade; }
+            }
+        }
+    }
+    {
+        unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
+        for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
+        for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
+            unsigned long long s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) atomicAdd(&F.counters[k], s);
+        }
+    }
+}
+
+} // namespace rtk

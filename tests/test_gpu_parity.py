@@ -18,13 +18,15 @@ def assert_bitwise(got, want, what):
                              f"gpu {got[y, x]} oracle {want[y, x]}")
 
 
-def run_gpu(tracer, buffers, first, n, mode=None, rows=None):
+def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=1, shade_threshold=24):
     params, spheres, tris, infos = buffers
     p = params.copy()
     if mode is not None:
         p["intersectMode"] = mode
     H = int(p["height"])
     tracer.set_rows(*(rows if rows else (0, H)))
+    tracer.set_option("kernel", kernel)
+    tracer.set_option("shade_threshold", shade_threshold)
     tracer.set_params(p)
     tracer.upload(spheres=spheres, triangles=tris, meshinfo=infos)
     tracer.reset_accum()
@@ -32,10 +34,11 @@ def run_gpu(tracer, buffers, first, n, mode=None, rows=None):
     return tracer.read_accum(), tracer.read_last_frame()
 
 
-def test_config1_spheres_bitwise(rtx, oracle, tracer):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_config1_spheres_bitwise(rtx, oracle, tracer, kernel):
     """configs[0]: 16 spheres, 256x256, 4 rays, 3 bounces — full image, frame 0."""
     b = rtx.scenes.config1().build_buffers()
-    acc, last = run_gpu(tracer, b, 0, 1)
+    acc, last = run_gpu(tracer, b, 0, 1, kernel=kernel)
     want_acc, want_last, _ = oracle.render(*b, 0, 1)
     assert_bitwise(last, want_last, "config1 currentFrame")
     assert_bitwise(acc, want_acc, "config1 resultTexture")
@@ -50,11 +53,13 @@ def test_config1_accumulate_three_frames(rtx, oracle, tracer):
     assert want_acc.max() <= 1.0
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_mesh_scene_bvh_bitwise(rtx, oracle, tracer, mode):
-    """Triangles through the BVH == the reference's flat chunk loop (mode 0) / brute force (mode 1)."""
+def test_mesh_scene_bvh_bitwise(rtx, oracle, tracer, mode, kernel):
+    """Triangles through the BVH == the reference's flat chunk loop (mode 0) / brute force (mode 1), for both
+    megakernel schedules."""
     b = rtx.scenes.mesh_test_scene(96, 64).build_buffers()
-    acc, last = run_gpu(tracer, b, 5, 2, mode=mode)
+    acc, last = run_gpu(tracer, b, 5, 2, mode=mode, kernel=kernel)
     want_acc, want_last, _ = oracle.render(*b, 5, 2, mode=mode)
     assert_bitwise(last, want_last, f"mesh scene frame 6 mode {mode}")
     assert_bitwise(acc, want_acc, f"mesh scene accum mode {mode}")
@@ -94,3 +99,13 @@ def test_counting_build_matches_oracle_ray_count(rtx, oracle, tracer):
     st = tracer.stats()
     _, cnt = oracle.render_frame(*b, 0)
     assert st["rays"] == cnt["rays"] and st["hits"] == cnt["hits"] and st["sphereTests"] == cnt["sphereTests"]
+
+
+@pytest.mark.parametrize("threshold", [1, 13, 64])
+def test_schedule_knobs_do_not_change_the_image(rtx, tracer, threshold):
+    """Streaming kernel at extreme shade thresholds == tile-per-wave kernel, odd image size (partial tiles)."""
+    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
+    ref, ref_last = run_gpu(tracer, b, 2, 2, kernel=0)
+    got, got_last = run_gpu(tracer, b, 2, 2, kernel=1, shade_threshold=threshold)
+    assert_bitwise(got, ref, f"stream(threshold={threshold}) vs tile kernel, accum")
+    assert_bitwise(got_last, ref_last, f"stream(threshold={threshold}) vs tile kernel, last frame")
