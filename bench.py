@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--kernel", type=int, default=-1, help="tuning: 0 tile-per-wave megakernel, 1 streaming megakernel (library default)")
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="name=value tuning option passed to rt_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
     return ap.parse_args()
@@ -117,6 +118,9 @@ def main():
         tr.set_option("shade_threshold", args.shade_threshold)
     if args.blocks_per_cu:
         tr.set_option("blocks_per_cu", args.blocks_per_cu)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        tr.set_option(k, int(v))
     strip = torch.zeros(rows, W, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def barrier():

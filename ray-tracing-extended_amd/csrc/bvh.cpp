@@ -109,13 +109,15 @@ struct Builder {
     }
 };
 
-// Widen a child box so the slab test stays conservative under float rounding: relative to the magnitude of
-// its own coordinates and, as a floor, to the magnitude G of the whole scene.
+// Widen a child box so the slab test stays conservative under float rounding.  The kernels evaluate
+// t = plane*inv - (o*inv) with one FMA: the absolute error is about (2|o| + |plane|) * 2^-24 in space, where the ray
+// origin o is the camera or a surface point.  G bounds both (scene coordinates and camera position), so a floor of
+// 2e-6*G is >10x that error; the relative term covers coordinates larger than the floor's scale.
 void pad_box(const Box& b, float G, float* mn, float* mx)
 {
     for (int a = 0; a < 3; ++a) {
         float m = std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
-        float e = 3e-5f * std::max(m, 0.05f * G) + 1e-30f;
+        float e = 3e-5f * m + 2e-6f * G + 1e-30f;
         mn[a] = b.mn[a] - e;
         mx[a] = b.mx[a] + e;
     }
@@ -123,14 +125,14 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 
 } // namespace
 
-void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, Bvh& out)
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, Bvh& out)
 {
     out.nodes.clear(); out.order.clear(); out.maxStack = 0; out.depth = 0;
     if (n_tris == 0) return;
 
     Builder B; B.pos = tri_pos; B.stride = stride_floats; B.n = n_tris;
     B.tbox.resize(n_tris); B.cent.resize(3 * (size_t)n_tris); B.idx.resize(n_tris);
-    float G = 0.f;
+    float G = origin_magnitude;
     for (uint32_t t = 0; t < n_tris; ++t) {
         const float* p = tri_pos + (size_t)t * stride_floats;
         Box b; b.reset(); b.grow(p); b.grow(p + 3); b.grow(p + 6);
@@ -144,6 +146,7 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, Bvh& out
     B.bn.reserve(2 * (size_t)n_tris / 2 + 16);
     int root = B.build_range(0, n_tris, 0);
     out.order = B.idx;
+    out.magnitude = G;
     out.depth = B.depth;
 
     // ---- collapse to 4-wide, breadth-first ----
@@ -154,8 +157,9 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, Bvh& out
         Node4 z; std::memset(&z, 0, sizeof z);
         for (int k = 0; k < 4; ++k) {
             z.child[k] = kEmpty;
-            z.minx[k] = z.miny[k] = z.minz[k] = std::numeric_limits<float>::quiet_NaN();
-            z.maxx[k] = z.maxy[k] = z.maxz[k] = std::numeric_limits<float>::quiet_NaN();
+            // an empty slot can never be entered: near planes at +inf, far planes at -inf for either ray direction
+            z.minx[k] = z.miny[k] = z.minz[k] = std::numeric_limits<float>::infinity();
+            z.maxx[k] = z.maxy[k] = z.maxz[k] = -std::numeric_limits<float>::infinity();
         }
         N.push_back(z);
         return (uint32_t)N.size() - 1u;

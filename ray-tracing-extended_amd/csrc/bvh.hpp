@@ -32,9 +32,11 @@ struct Bvh {
     std::vector<uint32_t> order;       // BVH order -> index into the uploaded triangle buffer
     int                   maxStack = 0; // worst-case number of entries the traversal stack can hold
     int                   depth = 0;
+    float                 magnitude = 0.f;  // G used for the box padding (scene coordinates and ray origins)
 };
 
-// tri_pos: 9 floats per triangle (posA, posB, posC).  scene_extent widens the absolute part of the padding.
-void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, Bvh& out);
+// tri_pos: 9 floats per triangle (posA, posB, posC).  origin_magnitude = largest |coordinate| a ray origin outside
+// the geometry can have (the camera): it widens the absolute part of the box padding.
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, Bvh& out);
 
 } // namespace rtbvh

@@ -14,6 +14,7 @@
 
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
+#include "rt_pool.hpp"
 
 namespace {
 
@@ -69,6 +70,10 @@ struct rt_ctx {
     int opt_kernel = 1;             // 0: k_trace (tile-per-wave), 1: k_stream (phase-scheduled, streaming pixels)
     int opt_shade_threshold = 24;
     int opt_blocks_per_cu = 0;      // 0: occupancy API
+    int opt_full_sort = 1;
+    int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
+    int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
+    DevBuf<uint32_t> d_gstack;
     rt_stats stats{};
 };
 
@@ -89,6 +94,18 @@ void pack_material(const rt_material& m, float4* out)
 {
     out[0] = f4(m.colour); out[1] = f4(m.emissionColour); out[2] = f4(m.specularColour);
     out[3] = make_float4(m.emissionStrength, m.smoothness, m.specularProbability, u2f((uint32_t)m.flag));
+}
+
+// Largest |coordinate| a camera-ray origin can have: camera position plus the defocus disc (frag :377-378).
+float camera_magnitude(const rt_params& p)
+{
+    float m = 0.f;
+    for (int a = 0; a < 3; ++a) m = std::max(m, std::fabs(p.worldSpaceCameraPos[a]));
+    float jitter = std::fabs(p.defocusStrength) / std::max(1.0f, (float)p.width);
+    float axis = 0.f;
+    for (int a = 0; a < 3; ++a)
+        axis = std::max(axis, std::fabs(p.camLocalToWorld[4 * a]) + std::fabs(p.camLocalToWorld[4 * a + 1]));
+    return m + jitter * axis;
 }
 
 // Re-layout of the uploaded buffers + BVH build.  Edge vectors and their cross product are the operands of
@@ -117,7 +134,7 @@ int build_scene(rt_ctx* c)
     for (size_t t = 0; t < nt; ++t) if (chunk_of[t] != 0xFFFFFFFFu) live.push_back((uint32_t)t);
     std::vector<float> pos(9 * live.size());
     for (size_t i = 0; i < live.size(); ++i) std::memcpy(&pos[9 * i], c->h_tris[live[i]].posA, 36);
-    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), c->bvh);
+    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), camera_magnitude(c->params), c->bvh);
 
     const size_t nl = live.size();
     std::vector<float4> geo(3 * nl), nrm(3 * nl);
@@ -198,6 +215,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
     if (n_frames < 0) return fail(c, -2, "n_frames < 0");
     RT_HIP(c, hipSetDevice(c->device));
+    if (!c->scene_dirty && camera_magnitude(c->params) > c->bvh.magnitude) c->scene_dirty = true;   // re-pad the boxes
     if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
     { int r = ensure_targets(c); if (r) return r; }
     if (c->target_pixels == 0 || n_frames == 0) return 0;
@@ -213,13 +231,20 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     F.row0 = c->target_row0; F.nrows = c->target_rows;
     F.tiles_x = (c->target_w + 7) / 8; F.tiles_y = (c->target_rows + 7) / 8;
     const bool stream = c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
+    const bool pooled = c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
+                        && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // k_stream's branch-free push writes up to 3 slots past the top
+    F.full_sort = c->opt_full_sort;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
     F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
 
-    const size_t lds = var == Variant::Flat ? 0 : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
+    const int pool_cap = std::max(1, std::min(c->opt_pool_stack, std::max(1, c->bvh.maxStack)));
+    const size_t lds = var == Variant::Flat ? 0
+                     : pooled ? (size_t)rtk::pool::wave_dwords(pool_cap) * sizeof(uint32_t) * rtk::kWavesPerBlock
+                              : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
     if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
+                   : pooled ? (var == Variant::Fast ? (const void*)rtk::k_pool<false> : (const void*)rtk::k_pool<true>)
                    : stream ? (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>)
                             : (var == Variant::Fast ? (const void*)rtk::k_trace<false, false> : (const void*)rtk::k_trace<true, false>);
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -227,12 +252,23 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::kBlock, lds));
     if (per_cu < 1) return fail(c, -7, "kernel does not fit a CU (LDS %zu B)", lds);
     const int ntiles = F.tiles_x * F.tiles_y;
-    const int want = (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
+    // k_pool waves own 128 pixel slots each: two tiles' worth
+    const int want = pooled ? (ntiles + 2 * rtk::kWavesPerBlock - 1) / (2 * rtk::kWavesPerBlock)
+                            : (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
     if (c->opt_blocks_per_cu > 0) per_cu = std::min(per_cu, c->opt_blocks_per_cu);
     const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
     rtk::StreamArgs A{};
     A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
     A.total_pixels = (unsigned int)ntiles * 64u;
+    rtk::PoolArgs PA{};
+    PA.total_pixels = A.total_pixels;
+    PA.trav_min_lanes = std::max(1, std::min(64, c->opt_trav_min_lanes));
+    PA.lds_stack_cap = pool_cap;
+    PA.gstack_stride = (unsigned int)grid * rtk::kBlock;
+    if (pooled && c->bvh.maxStack > pool_cap) {
+        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - pool_cap) * PA.gstack_stride));
+        PA.gstack = c->d_gstack.p;
+    }
 
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
@@ -240,7 +276,10 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         F.frame = first_frame + i;
         RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
         if (var == Variant::Flat) hipLaunchKernelGGL((rtk::k_trace<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
-        else if (stream) {
+        else if (pooled) {
+            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_pool<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
+            else                      hipLaunchKernelGGL((rtk::k_pool<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
+        } else if (stream) {
             if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
             else                      hipLaunchKernelGGL((rtk::k_stream<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
         } else {
@@ -336,7 +375,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -390,8 +429,11 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
 {
     if (!c) return -1;
     if (!name) return fail(c, -2, "null option name");
-    if (!std::strcmp(name, "kernel")) { if (value != 0 && value != 1) return fail(c, -2, "kernel must be 0 or 1"); c->opt_kernel = value; }
+    if (!std::strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail(c, -2, "kernel must be 0, 1 or 2"); c->opt_kernel = value; }
+    else if (!std::strcmp(name, "pool_stack")) { if (value < 1 || value > 64) return fail(c, -2, "pool_stack must be in [1,64]"); c->opt_pool_stack = value; }
+    else if (!std::strcmp(name, "trav_min_lanes")) { if (value < 1 || value > 64) return fail(c, -2, "trav_min_lanes must be in [1,64]"); c->opt_trav_min_lanes = value; }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
+    else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }
     else return fail(c, -2, "unknown option '%s'", name);
     return 0;

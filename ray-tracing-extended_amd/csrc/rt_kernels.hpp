@@ -44,6 +44,7 @@ struct FrameArgs {
     int row0, nrows;            // strip of the full image rendered by this launch
     int tiles_x, tiles_y;
     int stack_cap;              // LDS stack entries per lane
+    int full_sort;              // 1: sort all four children of a node by distance, 0: nearest first only
     float4* out_frame;          // [nrows*W] currentFrame
     float4* accum;              // [nrows*W] resultTexture
     unsigned int* tile_counter;
@@ -117,9 +118,66 @@ __device__ __forceinline__ bool ray_triangle(v3 o, v3 d, v3 A, v3 eAB, v3 eAC, v
     return det >= 1e-6f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
 }
 
+
+// ---- BVH4 node step ---------------------------------------------------------------------------------------
+// Per ray: the byte offsets (inside a 128-B node) of the float4 holding each axis' NEAR planes, chosen by the
+// sign of the direction component (far = the other one); t = plane * inv - o*inv is one FMA per plane — the
+// hierarchy only prunes, so its arithmetic is free to differ from the reference's (boxes are padded for it:
+// bvh.cpp pad_box).  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma/v_mul/v_add issue at ~2.5 cycles
+// per wave, v_min/v_max/v_cmp/v_cndmask at ~4.2 — so the slab test avoids per-axis min/max altogether.
+struct RaySlab {
+    v3 inv;             // 1 / d  (RayBoundingBox :179 — also used by the literal chunk filter)
+    v3 oinv;            // o * inv
+    uint32_t nx, ny, nz;   // byte offsets of the near-plane float4s (x: 0|48, y: 16|64, z: 32|80)
+};
+
+__device__ __forceinline__ RaySlab make_slab(v3 o, v3 d)
+{
+    RaySlab r;
+    r.inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.oinv = rtm::mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+    r.nx = d.x < 0.0f ? 48u : 0u;
+    r.ny = d.y < 0.0f ? 64u : 16u;
+    r.nz = d.z < 0.0f ? 80u : 32u;
+    return r;
+}
+
+// Tests the four child boxes of node `cur`, returns them sorted by entry distance (t0 <= t1 <= t2 <= t3, misses
+// carry t = +inf).  Empty slots hold (+inf, -inf) boxes and can never be hit.
+__device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint32_t cur, const RaySlab& r, float best_t, bool full_sort,
+                                          float& t0, float& t1, float& t2, float& t3,
+                                          uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3)
+{
+    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)cur * 128u;
+    const float4 px = *reinterpret_cast<const float4*>(nb + r.nx), qx = *reinterpret_cast<const float4*>(nb + (48u - r.nx));
+    const float4 py = *reinterpret_cast<const float4*>(nb + r.ny), qy = *reinterpret_cast<const float4*>(nb + (80u - r.ny));
+    const float4 pz = *reinterpret_cast<const float4*>(nb + r.nz), qz = *reinterpret_cast<const float4*>(nb + (112u - r.nz));
+    const uint4 ch = *reinterpret_cast<const uint4*>(nb + 96);
+    c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+    const float INF = __builtin_inff();
+#define RT_SLAB(K, TK)                                                                                                   \
+    {                                                                                                                    \
+        const float nx_ = __builtin_fmaf(px.K, r.inv.x, -r.oinv.x), fx_ = __builtin_fmaf(qx.K, r.inv.x, -r.oinv.x);      \
+        const float ny_ = __builtin_fmaf(py.K, r.inv.y, -r.oinv.y), fy_ = __builtin_fmaf(qy.K, r.inv.y, -r.oinv.y);      \
+        const float nz_ = __builtin_fmaf(pz.K, r.inv.z, -r.oinv.z), fz_ = __builtin_fmaf(qz.K, r.inv.z, -r.oinv.z);      \
+        const float tn_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx_, ny_), nz_), 0.0f);                        \
+        const float tf_ = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx_, fy_), fz_), best_t);                      \
+        TK = (tn_ <= tf_) ? tn_ : INF;                                                                                   \
+    }
+    RT_SLAB(x, t0) RT_SLAB(y, t1) RT_SLAB(z, t2) RT_SLAB(w, t3)
+#undef RT_SLAB
+#define RT_CSWAP(TA, CA, TB, CB) { const bool s_ = TB < TA; const float tt_ = s_ ? TB : TA, tu_ = s_ ? TA : TB;         \
+                                   const uint32_t ct_ = s_ ? CB : CA, cu_ = s_ ? CA : CB; TA = tt_; TB = tu_; CA = ct_; CB = cu_; }
+    // the nearest child must come first; a full sort of the other three (2 more exchanges) only refines the order in
+    // which they are popped later
+    RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
+    if (full_sort) { RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2) }
+#undef RT_CSWAP
+}
+
 // ---- closest hit: spheres, then BVH ---------------------------------------------------------------------
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_mode, v3 o, v3 d,
+__device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_mode, bool full_sort, v3 o, v3 d,
                                            uint32_t* stk, Counters& cnt)
 {
     Hit best; best.t = __builtin_inff(); best.id = kNone; best.u = 0.f; best.v = 0.f;
@@ -135,7 +193,8 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
     }
 
     if (S.nn > 0) {
-        const v3 inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);     // RayBoundingBox :179
+        const RaySlab slab = make_slab(o, d);
+        const v3 inv = slab.inv;                                        // RayBoundingBox :179
         int sp = 0;
         uint32_t cur = 0;                                               // root
         while (cur != kNone) {
@@ -143,30 +202,9 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
             while ((int)cur >= 0) {
                 if (COUNT) cnt.nodes++;
                 phase_tick<COUNT>(cnt, 0);
-                const float4* nb = S.nodes + (size_t)cur * 8;
-                const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
-                const uint4 ch = *reinterpret_cast<const uint4*>(nb + 6);
                 float t0, t1, t2, t3;
-                uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-#define RT_SLAB(K, TK, CK)                                                                           \
-                {                                                                                            \
-                    float ax = (mnx.K - o.x) * inv.x, bx = (mxx.K - o.x) * inv.x;                            \
-                    float ay = (mny.K - o.y) * inv.y, by = (mxy.K - o.y) * inv.y;                            \
-                    float az = (mnz.K - o.z) * inv.z, bz = (mxz.K - o.z) * inv.z;                            \
-                    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), \
-                                               __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));             \
-                    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), \
-                                               __builtin_fminf(__builtin_fmaxf(az, bz), best.t));           \
-                    TK = (tn <= tf && CK != kNone) ? tn : __builtin_inff();                                  \
-                }
-                RT_SLAB(x, t0, c0) RT_SLAB(y, t1, c1) RT_SLAB(z, t2, c2) RT_SLAB(w, t3, c3)
-#undef RT_SLAB
-                // sort the four (t, child) pairs ascending: 5-exchange network
-#define RT_CSWAP(TA, CA, TB, CB) { bool s_ = TB < TA; float tt_ = s_ ? TB : TA; float tu_ = s_ ? TA : TB;         \
-                                   uint32_t ct_ = s_ ? CB : CA; uint32_t cu_ = s_ ? CA : CB; TA = tt_; TB = tu_; CA = ct_; CB = cu_; }
-                RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
-                RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2)
-#undef RT_CSWAP
+                uint32_t c0, c1, c2, c3;
+                node_step(S.nodes, cur, slab, best.t, full_sort, t0, t1, t2, t3, c0, c1, c2, c3);
                 const float INF = __builtin_inff();
                 if (t3 < INF) { stk[sp * 64] = c3; ++sp; }
                 if (t2 < INF) { stk[sp * 64] = c2; ++sp; }
@@ -280,7 +318,7 @@ __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, 
 
 // One pixel of one frame: frag :356-389 as a flat state machine (see file header).
 template <bool COUNT, bool FLAT>
-__device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, int frame, int x, int y,
+__device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, int frame, int x, int y,
                                            uint32_t* stk, Counters& cnt)
 {
     const float* M = p.camLocalToWorld;
@@ -309,7 +347,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
     while (alive) {
         Hit h; v3 nrm_flat; uint32_t chunk_flat;
         if (FLAT) { h = closest_hit_flat(S, p.intersectMode, o, d, nrm_flat, chunk_flat); cnt.rays++; }
-        else      h = closest_hit<COUNT>(S, p.intersectMode, o, d, stk, cnt);
+        else      h = closest_hit<COUNT>(S, p.intersectMode, full_sort, o, d, stk, cnt);
 
         bool path_done;
         if (h.id != kNone) {
@@ -410,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DeviceScene S, FrameArgs F)
         const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + ly;
-            v3 c = render_pixel<COUNT, FLAT>(S, F.p, F.frame, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT>(S, F.p, F.full_sort != 0, F.frame, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[pi] = make_float4(c.x, c.y, c.z, 1.0f);                        // frag :388
             float4 prev = F.accum[pi];                                                 // Accumulate.shader:45-50

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
     int px = -1, ly = 0;                // current pixel (px < 0: none)
     uint32_t rng = 0;
     int sample = 0, bounce = 0;
-    v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total, inv = total;
+    v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
+    RaySlab slab = make_slab(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
     uint32_t cur = kNone; int sp = 0;
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                         }
                         live = true;
                         if (S.nn > 0) {
-                            inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // RayBoundingBox :179
+                            slab = make_slab(o, d);                                     // RayBoundingBox :179
                             cur = 0; sp = 0; mode = kModeTrav;
                         }
                     }
@@ -211,29 +212,9 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
             if (isTrav && (int)cur >= 0) {
                 if (COUNT) cnt.nodes++;
                 phase_tick<COUNT>(cnt, 0);
-                const float4* nb = S.nodes + (size_t)cur * 8;
-                const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
-                const uint4 ch = *reinterpret_cast<const uint4*>(nb + 6);
                 float t0, t1, t2, t3;
-                uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-#define RT_SLAB(K, TK, CK)                                                                                   \
-                {                                                                                            \
-                    float ax = (mnx.K - o.x) * inv.x, bx = (mxx.K - o.x) * inv.x;                            \
-                    float ay = (mny.K - o.y) * inv.y, by = (mxy.K - o.y) * inv.y;                            \
-                    float az = (mnz.K - o.z) * inv.z, bz = (mxz.K - o.z) * inv.z;                            \
-                    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), \
-                                               __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));             \
-                    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), \
-                                               __builtin_fminf(__builtin_fmaxf(az, bz), best.t));           \
-                    TK = (tn <= tf && CK != kNone) ? tn : INF;                                               \
-                }
-                RT_SLAB(x, t0, c0) RT_SLAB(y, t1, c1) RT_SLAB(z, t2, c2) RT_SLAB(w, t3, c3)
-#undef RT_SLAB
-#define RT_CSWAP(TA, CA, TB, CB) { bool s_ = TB < TA; float tt_ = s_ ? TB : TA; float tu_ = s_ ? TA : TB;         \
-                                   uint32_t ct_ = s_ ? CB : CA; uint32_t cu_ = s_ ? CA : CB; TA = tt_; TB = tu_; CA = ct_; CB = cu_; }
-                RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
-                RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2)
-#undef RT_CSWAP
+                uint32_t c0, c1, c2, c3;
+                node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
                 // branch-free push of the three farther children (far -> near); slots past the new top are garbage
                 stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
                 stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
@@ -265,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                         // the reference only reaches this triangle if its chunk's box test passes (:279)
                         uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
                         float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
-                        take = ray_bounding_box(o, inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
+                        take = ray_bounding_box(o, slab.inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
                     }
                     if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                 }

@@ -34,7 +34,7 @@ def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=1, shade_thr
     return tracer.read_accum(), tracer.read_last_frame()
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
 def test_config1_spheres_bitwise(rtx, oracle, tracer, kernel):
     """configs[0]: 16 spheres, 256x256, 4 rays, 3 bounces — full image, frame 0."""
     b = rtx.scenes.config1().build_buffers()
@@ -53,7 +53,7 @@ def test_config1_accumulate_three_frames(rtx, oracle, tracer):
     assert want_acc.max() <= 1.0
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_mesh_scene_bvh_bitwise(rtx, oracle, tracer, mode, kernel):
     """Triangles through the BVH == the reference's flat chunk loop (mode 0) / brute force (mode 1), for both
@@ -109,3 +109,20 @@ def test_schedule_knobs_do_not_change_the_image(rtx, tracer, threshold):
     got, got_last = run_gpu(tracer, b, 2, 2, kernel=1, shade_threshold=threshold)
     assert_bitwise(got, ref, f"stream(threshold={threshold}) vs tile kernel, accum")
     assert_bitwise(got_last, ref_last, f"stream(threshold={threshold}) vs tile kernel, last frame")
+
+
+@pytest.mark.parametrize("trav_min,pool_stack", [(1, 10), (32, 2), (64, 10), (40, 64)])
+def test_pool_kernel_knobs_do_not_change_the_image(rtx, tracer, trav_min, pool_stack):
+    """Wave-pool kernel (ballot/prefix-sum compaction) == tile-per-wave kernel for any suspend threshold and with the
+    traversal stack forced to spill to global memory (pool_stack=2), odd image size."""
+    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
+    ref, ref_last = run_gpu(tracer, b, 2, 2, kernel=0)
+    tracer.set_option("trav_min_lanes", trav_min)
+    tracer.set_option("pool_stack", pool_stack)
+    try:
+        got, got_last = run_gpu(tracer, b, 2, 2, kernel=2)
+    finally:
+        tracer.set_option("trav_min_lanes", 32)
+        tracer.set_option("pool_stack", 10)
+    assert_bitwise(got_last, ref_last, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, last frame")
+    assert_bitwise(got, ref, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, accum")
