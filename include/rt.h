@@ -136,9 +136,16 @@ int rt_upload_spheres  (rt_ctx* ctx, const rt_sphere*   spheres,  int n);
 int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris,     int n);
 int rt_upload_meshinfo (rt_ctx* ctx, const rt_meshinfo* meshinfo, int n);
 
-/* Tuning knobs; results never depend on them.  "kernel": 1 = phase-scheduled streaming megakernel (default),
- * 0 = tile-per-wave megakernel; "shade_threshold": lanes (1..64) that must wait for shading before the wave leaves
- * traversal; "blocks_per_cu": cap on resident workgroups per CU (0 = occupancy query).                          */
+/* Tuning knobs; the image never depends on them (tested bitwise).
+ *   "kernel"          0 = tile-per-wave megakernel k_trace (default), 1 = k_stream (resumable traversal, stragglers
+ *                     deferred), 2 = k_pool (pixel slots in LDS, in-wave ballot/prefix-sum compaction)
+ *   "max_leaf"        triangles per BVH leaf, 1..4 (default 2)
+ *   "full_sort"       1 = sort all four children of a node by entry distance (default), 0 = nearest first only
+ *   "lds_stack"       k_trace: traversal-stack entries kept in LDS, deeper ones spill to global memory (0 = all in LDS)
+ *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst
+ *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
+ *   "pool_stack", "trav_min_lanes"   k_pool: LDS stack entries per lane; in-flight lanes below which TRAVERSE is left
+ *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);
 
 /* Row strip rendered by this context: rows [row0, row0+nrows) of the full width x height image.

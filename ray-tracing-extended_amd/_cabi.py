@@ -14,7 +14,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_HERE, "librt_mi355x.so")   # RTX_LIB: A/B builds of the same ABI
 
 # ---- buffer layouts ------------------------------------------------------------------------------------------
 MATERIAL = np.dtype([

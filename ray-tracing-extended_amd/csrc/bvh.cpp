@@ -46,6 +46,7 @@ struct Builder {
     std::vector<uint32_t> idx;
     std::vector<BNode>    bn;
     int depth = 0;
+    int max_leaf = kMaxLeaf;
 
     int build_range(uint32_t first, uint32_t count, int level)
     {
@@ -59,7 +60,7 @@ struct Builder {
             cb.grow(&cent[3 * (size_t)idx[i]]);
         }
         bn[me].box = b;
-        if (count <= (uint32_t)kMaxLeaf) {
+        if (count <= (uint32_t)max_leaf) {
             bn[me].first = first; bn[me].count = count;
             return me;
         }
@@ -125,12 +126,13 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 
 } // namespace
 
-void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, Bvh& out)
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out)
 {
     out.nodes.clear(); out.order.clear(); out.maxStack = 0; out.depth = 0;
     if (n_tris == 0) return;
 
     Builder B; B.pos = tri_pos; B.stride = stride_floats; B.n = n_tris;
+    B.max_leaf = std::min(std::max(max_leaf, 1), kMaxLeaf);
     B.tbox.resize(n_tris); B.cent.resize(3 * (size_t)n_tris); B.idx.resize(n_tris);
     float G = origin_magnitude;
     for (uint32_t t = 0; t < n_tris; ++t) {

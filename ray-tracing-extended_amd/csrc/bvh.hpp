@@ -37,6 +37,7 @@ struct Bvh {
 
 // tri_pos: 9 floats per triangle (posA, posB, posC).  origin_magnitude = largest |coordinate| a ray origin outside
 // the geometry can have (the camera): it widens the absolute part of the box padding.
-void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, Bvh& out);
+// max_leaf: triangles per leaf (1..kMaxLeaf).
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out);
 
 } // namespace rtbvh

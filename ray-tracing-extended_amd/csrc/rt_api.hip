@@ -67,10 +67,13 @@ struct rt_ctx {
 
     rtbvh::Bvh bvh;
     int n_cu = 0;
-    int opt_kernel = 1;             // 0: k_trace (tile-per-wave), 1: k_stream (phase-scheduled, streaming pixels)
-    int opt_shade_threshold = 24;
+    int opt_kernel = 0;             // 0: k_trace (tile per wave), 1: k_stream (resumable traversal), 2: k_pool (in-wave compaction)
+    int opt_shade_threshold = 56;
+    int opt_tile_sync = 1;
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 1;
+    int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
+    int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
     int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
     DevBuf<uint32_t> d_gstack;
@@ -134,7 +137,7 @@ int build_scene(rt_ctx* c)
     for (size_t t = 0; t < nt; ++t) if (chunk_of[t] != 0xFFFFFFFFu) live.push_back((uint32_t)t);
     std::vector<float> pos(9 * live.size());
     for (size_t i = 0; i < live.size(); ++i) std::memcpy(&pos[9 * i], c->h_tris[live[i]].posA, 36);
-    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), camera_magnitude(c->params), c->bvh);
+    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), camera_magnitude(c->params), c->opt_max_leaf, c->bvh);
 
     const size_t nl = live.size();
     std::vector<float4> geo(3 * nl), nrm(3 * nl);
@@ -234,6 +237,8 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     const bool pooled = c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // k_stream's branch-free push writes up to 3 slots past the top
+    const bool tile_kernel = !stream && !pooled && var != Variant::Flat;
+    if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     F.full_sort = c->opt_full_sort;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
     F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
@@ -260,11 +265,16 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     rtk::StreamArgs A{};
     A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
     A.total_pixels = (unsigned int)ntiles * 64u;
+    A.tile_sync = c->opt_tile_sync;
     rtk::PoolArgs PA{};
     PA.total_pixels = A.total_pixels;
     PA.trav_min_lanes = std::max(1, std::min(64, c->opt_trav_min_lanes));
     PA.lds_stack_cap = pool_cap;
     PA.gstack_stride = (unsigned int)grid * rtk::kBlock;
+    if (tile_kernel && c->bvh.maxStack > F.stack_cap) {
+        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - F.stack_cap) * PA.gstack_stride));
+        F.gstack = c->d_gstack.p; F.gstack_stride = PA.gstack_stride;
+    }
     if (pooled && c->bvh.maxStack > pool_cap) {
         RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - pool_cap) * PA.gstack_stride));
         PA.gstack = c->d_gstack.p;
@@ -433,6 +443,9 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "pool_stack")) { if (value < 1 || value > 64) return fail(c, -2, "pool_stack must be in [1,64]"); c->opt_pool_stack = value; }
     else if (!std::strcmp(name, "trav_min_lanes")) { if (value < 1 || value > 64) return fail(c, -2, "trav_min_lanes must be in [1,64]"); c->opt_trav_min_lanes = value; }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
+    else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }
+    else if (!std::strcmp(name, "max_leaf")) { if (value < 1 || value > rtbvh::kMaxLeaf) return fail(c, -2, "max_leaf must be in [1,4]"); if (value != c->opt_max_leaf) c->scene_dirty = true; c->opt_max_leaf = value; }
+    else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }
     else return fail(c, -2, "unknown option '%s'", name);

@@ -45,6 +45,8 @@ struct FrameArgs {
     int tiles_x, tiles_y;
     int stack_cap;              // LDS stack entries per lane
     int full_sort;              // 1: sort all four children of a node by distance, 0: nearest first only
+    uint32_t* gstack;           // overflow of the traversal stack beyond stack_cap ([entry][lane of the launch]); may be null
+    unsigned int gstack_stride; // lanes of the launch
     float4* out_frame;          // [nrows*W] currentFrame
     float4* accum;              // [nrows*W] resultTexture
     unsigned int* tile_counter;
@@ -62,6 +64,22 @@ struct Hit {
 
 // Work counters (rays always; the rest in the counting build).  phase_lanes[k] / (64 * phase_execs[k]) is the lane
 // utilisation of phase k (0 node step, 1 triangle test, 2 hit shading, 3 environment, 4 camera ray).
+// Per-lane traversal stack: the first `cap` entries in LDS (stack[entry][lane]: one bank per lane, conflict-free), deeper
+// entries — rare: the LDS part is sized for the depths rays actually reach — in a global overflow area.
+struct TravStack {
+    uint32_t* lds; uint32_t* glb; int cap; unsigned int stride;
+    __device__ __forceinline__ void push(int& sp, uint32_t v) const
+    {
+        if (sp < cap) lds[sp * 64] = v; else glb[(size_t)(sp - cap) * stride] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ uint32_t pop(int& sp) const
+    {
+        --sp;
+        return sp < cap ? lds[sp * 64] : glb[(size_t)(sp - cap) * stride];
+    }
+};
+
 struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; };
 constexpr int kNumCounters = 15;
 
@@ -178,7 +196,7 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
 // ---- closest hit: spheres, then BVH ---------------------------------------------------------------------
 template <bool COUNT>
 __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_mode, bool full_sort, v3 o, v3 d,
-                                           uint32_t* stk, Counters& cnt)
+                                           const TravStack& stk, Counters& cnt)
 {
     Hit best; best.t = __builtin_inff(); best.id = kNone; best.u = 0.f; best.v = 0.f;
     cnt.rays++;                                  // rays are always counted (one add per cast)
@@ -206,11 +224,11 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                 uint32_t c0, c1, c2, c3;
                 node_step(S.nodes, cur, slab, best.t, full_sort, t0, t1, t2, t3, c0, c1, c2, c3);
                 const float INF = __builtin_inff();
-                if (t3 < INF) { stk[sp * 64] = c3; ++sp; }
-                if (t2 < INF) { stk[sp * 64] = c2; ++sp; }
-                if (t1 < INF) { stk[sp * 64] = c1; ++sp; }
+                if (t3 < INF) stk.push(sp, c3);
+                if (t2 < INF) stk.push(sp, c2);
+                if (t1 < INF) stk.push(sp, c1);
                 if (t0 < INF) cur = c0;
-                else if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                else if (sp > 0) cur = stk.pop(sp);
                 else cur = kNone;
             }
             // ---- leaf
@@ -242,7 +260,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                         if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                     }
                 }
-                if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                if (sp > 0) cur = stk.pop(sp);
                 else cur = kNone;
             }
         }
@@ -293,7 +311,10 @@ __device__ __forceinline__ v3 environment_light(const rt_params& p, v3 d)
     float skyGradientT = rtm::pow_(rtm::smoothstep(0.0f, 0.4f, d.y), 0.35f);
     float groundToSkyT = rtm::smoothstep(-0.01f, 0.0f, d.y);
     v3 skyGradient = rtm::lerp(ld3(p.skyColourHorizon), ld3(p.skyColourZenith), skyGradientT);
-    float sun = rtm::pow_(rtm::fmax_(0.0f, rtm::dot(d, ld3(p.worldSpaceLightPos0))), p.sunFocus) * p.sunIntensity;
+    // sunIntensity == +0 (e.g. Chess.unity:30185): the base max(0, dot) is finite, >= 0 and at most 1 + a few ulp, so for
+    // 1 <= sunFocus <= 1e6 pow() is finite and >= 0 and the product is exactly +0; skip the transcendentals, keep the adds.
+    float sun = (__float_as_uint(p.sunIntensity) == 0u && p.sunFocus >= 1.0f && p.sunFocus <= 1.0e6f) ? 0.0f
+              : rtm::pow_(rtm::fmax_(0.0f, rtm::dot(d, ld3(p.worldSpaceLightPos0))), p.sunFocus) * p.sunIntensity;
     v3 composite = rtm::lerp(ld3(p.groundColour), skyGradient, groundToSkyT);
     float sunTerm = sun * ((groundToSkyT >= 1.0f) ? 1.0f : 0.0f);
     return rtm::mk(composite.x + sunTerm, composite.y + sunTerm, composite.z + sunTerm);
@@ -319,7 +340,7 @@ __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, 
 // One pixel of one frame: frag :356-389 as a flat state machine (see file header).
 template <bool COUNT, bool FLAT>
 __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, int frame, int x, int y,
-                                           uint32_t* stk, Counters& cnt)
+                                           const TravStack& stk, Counters& cnt)
 {
     const float* M = p.camLocalToWorld;
     const uint32_t W = (uint32_t)p.width;
@@ -425,15 +446,21 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
     return rtm::mk(total.x / n, total.y / n, total.z / n);                             // :387
 }
 
+#ifndef RT_KTRACE_ATTR
+#define RT_KTRACE_ATTR
+#endif
 constexpr int kBlock = 256;         // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 
 template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(kBlock) void k_trace(DeviceScene S, FrameArgs F)
+__global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, FrameArgs F)
 {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* stk = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
+    TravStack stk;
+    stk.lds = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
+    stk.cap = F.stack_cap; stk.stride = F.gstack_stride;
+    stk.glb = F.gstack ? F.gstack + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
     Counters cnt = {};
     const int ntiles = F.tiles_x * F.tiles_y;
     const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48

@@ -1,20 +1,17 @@
 // rt_stream.hpp — the streaming megakernel: same per-pixel arithmetic as k_trace (rt_kernels.hpp), different
 // wave-level schedule.
 //
-// k_trace runs, per loop iteration, one complete closest-hit query for all 64 lanes and then shades all of them:
-// the wave pays for the longest traversal in it (measured on the 100k-triangle workload: 24 node steps executed
-// per 9 needed, lane utilisation 37 % in node steps and 29 % in triangle tests).  Here traversal is *resumable*
-// and the wave picks, step by step, the phase most of its lanes are waiting for:
-//
-//     NODE   one BVH4 node step for the lanes whose current reference is an internal node
-//     TRI    one RayTriangle test for the lanes whose current reference is a leaf
-//     SHADE  for the lanes whose query is complete: hit/miss shading, next bounce or next sample or next pixel,
-//            new ray, sphere loop, traversal reset
-//
-// SHADE runs when at least `shade_threshold` lanes wait for it (or nothing else can run); otherwise NODE or TRI,
-// whichever has more lanes.  Lanes not in the chosen phase keep their state in registers and simply sit out the
-// step.  A lane that finishes its pixel (all NumRaysPerPixel samples) writes it (frame + fused accumulate) and
-// pulls the next pixel index from a global counter (tile-major order, 8x8 tiles), so there is no per-tile tail.
+// k_trace binds an 8x8 tile to a wave and, per loop iteration, runs one complete closest-hit query for all 64 lanes
+// before shading them: the wave pays for the longest traversal in it (measured on the 100k-triangle workload: 24 node
+// steps executed per 9 needed) and for the slowest pixel of its tile.  Here
+//   * traversal is *resumable*: a while-while burst (node steps until no lane holds an internal node, then whole
+//     leaves) ends as soon as `shade_threshold` lanes have a complete query; the few stragglers keep cur / sp / best
+//     hit / slab constants in registers, sit out the SHADE pass, and continue in the next burst next to the other
+//     lanes' new rays — the wave no longer waits for its longest ray;
+//   * SHADE (hit/miss shading, next bounce or next sample or next pixel, new ray, sphere loop, traversal reset) runs
+//     for the lanes whose query is complete;
+//   * a lane that finishes its pixel (all NumRaysPerPixel samples) writes it (frame + fused accumulate) and pulls the
+//     next pixel index from a global counter (tile-major order, 8x8 tiles), so there is no per-tile tail.
 //
 // Nothing about a pixel's own sequence of operations changes (same RNG chain, same closest-hit arithmetic, same
 // tie-break), so the image is bit-identical to k_trace and to the oracle.
@@ -26,9 +23,10 @@ namespace rtk {
 struct StreamArgs {
     int shade_threshold;        // lanes waiting for SHADE that trigger it
     unsigned int total_pixels;  // tiles_x * tiles_y * 64 (tile-major enumeration, padded)
+    int tile_sync;              // 1: a wave takes a whole 8x8 tile at a time (coherent lanes), 0: lanes refill pixel by pixel
 };
 
-enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2 };
+enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
@@ -52,7 +50,8 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
     cam.focusPoint = rtm::mk(0.f, 0.f, 0.f);
 
     // ---- per-lane state -------------------------------------------------------------------------------------
-    uint32_t mode = kModeShade;         // every lane starts by asking for a pixel
+    uint32_t mode = A.tile_sync ? kModeWait : kModeShade;   // every lane starts by asking for a pixel (or the wave for a tile)
+    bool fresh = false;                 // the lane was just given a pixel: its first camera ray is due
     int px = -1, ly = 0;                // current pixel (px < 0: none)
     uint32_t rng = 0;
     int sample = 0, bounce = 0;
@@ -63,17 +62,32 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
 
     for (;;) {
-        const bool isTrav = mode == kModeTrav;
-        const unsigned long long mNode = __ballot(isTrav && (int)cur >= 0);
-        const unsigned long long mLeaf = __ballot(isTrav && (int)cur < 0);
-        const unsigned long long mShade = __ballot(mode == kModeShade);
-        const int nNode = __popcll(mNode), nLeaf = __popcll(mLeaf), nShade = __popcll(mShade);
-        if (nNode + nLeaf + nShade == 0) break;                                       // every lane is dead
+        const int nTrav = __popcll(__ballot(mode == kModeTrav)), nShade = __popcll(__ballot(mode == kModeShade));
+        if (nTrav + nShade == 0) {
+            if (!A.tile_sync) break;                                                  // every lane is dead
+            // ---- the whole wave is done with its tile: take the next one (tile-major order)
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(F.tile_counter, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= A.total_pixels) break;
+            const unsigned int tile = base >> 6;
+            const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (lane & 7);
+            const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
+            if (x < p.width && yy < F.nrows) {
+                px = x; ly = yy;
+                rng = ((uint32_t)(F.row0 + yy) * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;          // :361-362
+                total = rtm::mk(0.f, 0.f, 0.f);
+                sample = 0; live = false; fresh = true;
+                mode = kModeShade;
+            }
+            continue;
+        }
 
-        if (nShade >= A.shade_threshold || nNode + nLeaf == 0) {
+        if (nShade >= A.shade_threshold || nTrav == 0) {
             // ================================ SHADE ================================
             if (mode == kModeShade) {
-                bool need_ray = false;                  // a camera ray must be generated
+                bool need_ray = fresh;                  // a camera ray must be generated
+                fresh = false;
                 bool path_done = false;
                 if (live) {
                     if (best.id != kNone) {
@@ -144,12 +158,13 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                             acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
                             F.accum[pi] = acc;
                             px = -1;
+                            if (A.tile_sync) mode = kModeWait;      // idle until the wave's whole tile is done
                         } else need_ray = true;
                     }
                     live = false;
                 }
                 // ---- pixel refill: tile-major global order; indices outside the strip are skipped
-                while (true) {
+                while (!A.tile_sync) {
                     const unsigned long long need = __ballot(px < 0 && mode != kModeDead);
                     if (need == 0) break;
                     if (px < 0 && mode != kModeDead) {
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                         }
                     }
                 }
-                if (mode != kModeDead) {
+                if (mode == kModeShade) {
                     if (need_ray) {
                         // ---- frag :364-382
                         phase_tick<COUNT>(cnt, 4);
@@ -207,53 +222,61 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                     }
                 }
             }
-        } else if (nNode >= nLeaf) {
-            // ================================ NODE =================================
-            if (isTrav && (int)cur >= 0) {
-                if (COUNT) cnt.nodes++;
-                phase_tick<COUNT>(cnt, 0);
-                float t0, t1, t2, t3;
-                uint32_t c0, c1, c2, c3;
-                node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
-                // branch-free push of the three farther children (far -> near); slots past the new top are garbage
-                stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
-                stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
-                stk[sp * 64] = c1; sp += (t1 < INF) ? 1 : 0;
-                if (t0 < INF) cur = c0;
-                else if (sp > 0) { --sp; cur = stk[sp * 64]; }
-                else { cur = kNone; mode = kModeShade; }
-            }
         } else {
-            // ================================ TRI ==================================
-            if (isTrav && (int)cur < 0) {
-                const uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
-                const float4* tg = S.tri_geo + (size_t)ti * 3;
-                const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
-                float dst, u, v;
-                if (COUNT) cnt.tris++;
-                phase_tick<COUNT>(cnt, 1);
-                const bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
-                                              rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
-                if (hit && dst <= best.t) {
-                    bool take = dst < best.t;
-                    if (!take && (best.id & kTriBit) && best.id != kNone) {
-                        // equal dst: the reference keeps the triangle that comes first in the buffer
-                        uint32_t oc = __float_as_uint(S.tri_nrm[(size_t)ti * 3 + 1].w);
-                        uint32_t ob = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3 + 1].w);
-                        take = oc < ob;
+            // ================================ TRAVERSAL BURST ================================
+            // while-while over the lanes in flight: node steps until no lane holds an internal node, then every lane
+            // tests its whole leaf.  The burst ends when all queries are complete, or as soon as `shade_threshold`
+            // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
+            for (;;) {
+                while (__ballot(mode == kModeTrav && (int)cur >= 0) != 0) {
+                    if (mode == kModeTrav && (int)cur >= 0) {
+                        if (COUNT) cnt.nodes++;
+                        phase_tick<COUNT>(cnt, 0);
+                        float t0, t1, t2, t3;
+                        uint32_t c0, c1, c2, c3;
+                        node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
+                        // branch-free push of the three farther children (far -> near); slots past the new top are garbage
+                        stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
+                        stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
+                        stk[sp * 64] = c1; sp += (t1 < INF) ? 1 : 0;
+                        if (t0 < INF) cur = c0;
+                        else if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                        else { cur = kNone; mode = kModeShade; }
                     }
-                    if (take && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
-                        // the reference only reaches this triangle if its chunk's box test passes (:279)
-                        uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
-                        float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
-                        take = ray_bounding_box(o, slab.inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
-                    }
-                    if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                 }
-                // next triangle of the leaf (reference = kLeafBit | first << 2 | count-1), or pop
-                if (cur & 3u) cur += 3u;            // first + 1, count - 1
-                else if (sp > 0) { --sp; cur = stk[sp * 64]; }
-                else { cur = kNone; mode = kModeShade; }
+                if (mode == kModeTrav) {            // (int)cur < 0: a leaf = kLeafBit | first << 2 | count-1
+                    uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
+                    const uint32_t last = ti + (cur & 3u);
+                    for (; ti <= last; ++ti) {
+                        const float4* tg = S.tri_geo + (size_t)ti * 3;
+                        const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                        float dst, u, v;
+                        if (COUNT) cnt.tris++;
+                        phase_tick<COUNT>(cnt, 1);
+                        const bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
+                                                      rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
+                        if (hit && dst <= best.t) {
+                            bool take = dst < best.t;
+                            if (!take && (best.id & kTriBit) && best.id != kNone) {
+                                // equal dst: the reference keeps the triangle that comes first in the buffer
+                                uint32_t oc = __float_as_uint(S.tri_nrm[(size_t)ti * 3 + 1].w);
+                                uint32_t ob = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3 + 1].w);
+                                take = oc < ob;
+                            }
+                            if (take && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
+                                // the reference only reaches this triangle if its chunk's box test passes (:279)
+                                uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
+                                float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
+                                take = ray_bounding_box(o, slab.inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
+                            }
+                            if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
+                        }
+                    }
+                    if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                    else { cur = kNone; mode = kModeShade; }
+                }
+                if (__ballot(mode == kModeTrav) == 0) break;
+                if (__popcll(__ballot(mode == kModeShade)) >= A.shade_threshold) break;
             }
         }
     }

@@ -18,7 +18,7 @@ def assert_bitwise(got, want, what):
                              f"gpu {got[y, x]} oracle {want[y, x]}")
 
 
-def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=1, shade_threshold=24):
+def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=0, shade_threshold=56, tile_sync=1):
     params, spheres, tris, infos = buffers
     p = params.copy()
     if mode is not None:
@@ -27,6 +27,7 @@ def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=1, shade_thr
     tracer.set_rows(*(rows if rows else (0, H)))
     tracer.set_option("kernel", kernel)
     tracer.set_option("shade_threshold", shade_threshold)
+    tracer.set_option("tile_sync", tile_sync)
     tracer.set_params(p)
     tracer.upload(spheres=spheres, triangles=tris, meshinfo=infos)
     tracer.reset_accum()
@@ -101,12 +102,14 @@ def test_counting_build_matches_oracle_ray_count(rtx, oracle, tracer):
     assert st["rays"] == cnt["rays"] and st["hits"] == cnt["hits"] and st["sphereTests"] == cnt["sphereTests"]
 
 
+@pytest.mark.parametrize("tile_sync", [0, 1])
 @pytest.mark.parametrize("threshold", [1, 13, 64])
-def test_schedule_knobs_do_not_change_the_image(rtx, tracer, threshold):
-    """Streaming kernel at extreme shade thresholds == tile-per-wave kernel, odd image size (partial tiles)."""
+def test_schedule_knobs_do_not_change_the_image(rtx, tracer, threshold, tile_sync):
+    """Resumable-traversal kernel at extreme shade thresholds, tile-at-a-time and pixel-at-a-time refill == the
+    tile-per-wave kernel, odd image size (partial tiles)."""
     b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
     ref, ref_last = run_gpu(tracer, b, 2, 2, kernel=0)
-    got, got_last = run_gpu(tracer, b, 2, 2, kernel=1, shade_threshold=threshold)
+    got, got_last = run_gpu(tracer, b, 2, 2, kernel=1, shade_threshold=threshold, tile_sync=tile_sync)
     assert_bitwise(got, ref, f"stream(threshold={threshold}) vs tile kernel, accum")
     assert_bitwise(got_last, ref_last, f"stream(threshold={threshold}) vs tile kernel, last frame")
 
