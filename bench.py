@@ -75,12 +75,15 @@ def cpu_baseline(rtx, buffers):
     if per_px * n * n > 30:
         p["numRaysPerPixel"] = max(1, int(rays_pp * 20 / (per_px * n * n)))
     x0, y0 = (W - n) // 2, (H - n) // 2
-    t0 = time.time()
-    _, c = orc.render_frame(p, spheres, tris, infos, 0, (x0, y0, x0 + n, y0 + n))
+    frames = max(1, min(64, int(10.0 / max(per_px * n * n, 1e-3))))       # cheap scenes: several frames, ~10 s in all
+    rays, t0 = 0, time.time()
+    for f in range(frames):
+        _, c = orc.render_frame(p, spheres, tris, infos, f, (x0, y0, x0 + n, y0 + n))
+        rays += c["rays"]
     dt = time.time() - t0
-    return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": c["threads"], "kind": "port",
-            "sample": f"{n}x{n} centre crop of frame 0, {int(p['numRaysPerPixel'])} rays/pixel, FLAT_CHUNKS "
-                      f"(the reference's chunk loop), {c['rays']} rays in {dt:.1f} s"}
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": c["threads"], "kind": "port",
+            "sample": f"{n}x{n} centre crop of frame(s) 0..{frames - 1}, {int(p['numRaysPerPixel'])} rays/pixel, FLAT_CHUNKS "
+                      f"(the reference's chunk loop), {rays} rays in {dt:.1f} s"}
 
 
 def main():
