@@ -10,9 +10,10 @@ on the ~100k-triangle scene (configs[2]).  A *step* is one frame = one trace+acc
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-N > 1: the image is cut into N contiguous row strips (seeds use global pixel coordinates, so the image does not
-depend on the decomposition), every rank traces its strip for all K frames, and one RCCL gather to rank 0 at the end
-collects the accumulated strips (inside the timed region).  Total work is fixed -> "scaling": "strong".
+N > 1: the image's 8-row bands are dealt round-robin to the N ranks (row-strip decomposition, interleaved so that sky
+rows and object rows spread evenly; seeds use global pixel coordinates, so the image does not depend on the
+decomposition), every rank traces its rows for all K frames, and one RCCL gather to rank 0 at the end collects the
+accumulated rows (inside the timed region).  Total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option passed to rt_set_option")
+    ap.add_argument("--decomposition", choices=["bands", "strips"], default="bands",
+                    help="N>1: interleaved 8-row bands (balanced, default) or N contiguous strips")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
     return ap.parse_args()
@@ -100,21 +104,34 @@ def main():
     rtx = rtx_pkg.load()
 
     dist = None
+    dev_index = int(os.environ.get("RTX_BENCH_DEVICE", local_rank))      # rehearsal on a 1-GPU box: all ranks on device 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    comm_dev = f"cuda:{dev_index}" if args.backend == "nccl" else "cpu"
 
     mgr = build_workload(rtx, args)
     buffers = mgr.build_buffers()
     params, spheres, tris, infos = buffers
     W, H = int(params["width"]), int(params["height"])
-    row0, nrows, rows = rtx.distributed.row_strip(H, world, rank)
+    banded = world > 1 and args.decomposition == "bands"
+    if banded:      # 8-row bands dealt round-robin: sky rows and object rows spread evenly over the ranks
+        my_rows = rtx.distributed.band_rows(H, world, rank)
+        row0, nrows, rows = rank * 8, len(my_rows), rtx.distributed.band_rows_padded(H, world)
+    else:
+        row0, nrows, rows = rtx.distributed.row_strip(H, world, rank)
 
-    tr = rtx.Tracer(local_rank)
+    tr = rtx.Tracer(dev_index)
     tr.set_params(params)
     tr.upload(spheres=spheres, triangles=tris, meshinfo=infos)
-    tr.set_rows(row0, nrows)
+    if banded:
+        tr.set_bands(rank, world)
+    else:
+        tr.set_rows(row0, nrows)
     if args.kernel >= 0:
         tr.set_option("kernel", args.kernel)
     if args.shade_threshold:
@@ -124,7 +141,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         tr.set_option(k, int(v))
-    strip = torch.zeros(rows, W, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+    strip = torch.zeros(rows, W, 4, dtype=torch.float32, device=f"cuda:{dev_index}")
 
     def barrier():
         if dist is not None:
@@ -133,8 +150,9 @@ def main():
 
     # ---- warmup (untimed): also builds the BVH and uploads
     tr.render(0, max(args.warmup, 0))
+    gather = rtx.distributed.gather_image_banded if banded else rtx.distributed.gather_image
     if dist is not None:                      # warm the RCCL communicator
-        rtx.distributed.gather_image(strip, H, dist)
+        gather(strip.to(comm_dev), H, dist)
     # ---- timed region: exactly K steps + the frame-end gather
     tr.reset_accum()
     barrier()
@@ -142,11 +160,11 @@ def main():
     tr.render(0, args.steps)
     if dist is not None:
         tr.copy_accum_to_device(strip.data_ptr(), nrows * W * 4)
-        image = rtx.distributed.gather_image(strip, H, dist)      # [H, W, 4] on rank 0
+        image = gather(strip.to(comm_dev), H, dist)   # [H, W, 4] on rank 0
     barrier()
     dt = time.perf_counter() - t0
     st = tr.stats()
-    rays = torch.tensor([float(st["rays"]), dt, st["totalKernelMs"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+    rays = torch.tensor([float(st["rays"]), dt, st["totalKernelMs"]], dtype=torch.float64, device=comm_dev)
     if dist is not None:
         tmax = rays.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -174,7 +192,7 @@ def main():
             try:
                 tj = json.load(open(tf))
                 key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}"
-                traffic = tj.get(key, {}).get("bytes_per_launch")
+                traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None   # measured for the N=1 launch
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -208,7 +226,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{names[args.config]}, {W}x{H}, {int(params['numRaysPerPixel'])} rays/pixel/frame "
                                f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, PCG, FLAT_CHUNKS semantics",
-                   "decomposition": f"{world} row strip(s) + one RCCL gather" if world > 1 else "single GPU",
+                   "decomposition": (f"{world} ranks, " + ("interleaved 8-row bands" if banded else "contiguous row strips")
+                                     + " + one RCCL gather") if world > 1 else "single GPU",
                    "rays_per_frame": int(total_rays / max(args.steps, 1)),
                    "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres))},
         "roofline": roofline, "cpu_baseline": cpu,

@@ -152,6 +152,10 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value);
  * Seeds use global pixel coordinates (RayTracing.shader:360-362) so the image is decomposition-invariant.
  * Default = the whole image.                                                                          */
 int rt_set_rows(rt_ctx* ctx, int row0, int nrows);
+/* Interleaved decomposition for load balance: this context renders the 8-row bands first_band, first_band +
+ * band_stride, first_band + 2*band_stride, ... (band b = image rows [8b, 8b+8)); its targets hold those rows back to
+ * back.  (0, 1) is the whole image.  Overrides rt_set_rows; rt_set_rows switches back to one contiguous strip.       */
+int rt_set_bands(rt_ctx* ctx, int first_band, int band_stride);
 
 /* One frame = Graphics.Blit(null, currentFrame, rayTracingMaterial) with "Frame" = frame_index, followed by
  * the Accumulate blit with "_Frame" = frame_index (RayTracingManager.cs:74-81).  Returns after the

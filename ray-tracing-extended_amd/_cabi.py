@@ -51,7 +51,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_params", "rt_upload_spheres",
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
-    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option",
+    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def load_library() -> ctypes.CDLL:
         getattr(lib, n).argtypes = [c_void_p, c_void_p, c_int]
     lib.rt_set_rows.argtypes = [c_void_p, c_int, c_int]
     lib.rt_set_option.argtypes = [c_void_p, c_char_p, c_int]
+    lib.rt_set_bands.argtypes = [c_void_p, c_int, c_int]
     lib.rt_render_frame.argtypes = [c_void_p, c_int]
     lib.rt_render_frame_flat.argtypes = [c_void_p, c_int]
     lib.rt_render.argtypes = [c_void_p, c_int, c_int]
@@ -163,6 +164,11 @@ class Tracer:
     def set_rows(self, row0: int, nrows: int):
         self._rows = (row0, nrows)
         self._check(self._lib.rt_set_rows(self._ctx, row0, nrows), "rt_set_rows")
+
+    def set_bands(self, first_band: int, band_stride: int, height: int = None):
+        H = int(self._params["height"]) if height is None else height
+        self._rows = (first_band * 8, sum(min(8, H - y) for y in range(first_band * 8, H, band_stride * 8)))
+        self._check(self._lib.rt_set_bands(self._ctx, first_band, band_stride), "rt_set_bands")
 
     def set_option(self, name: str, value: int):
         self._check(self._lib.rt_set_option(self._ctx, name.encode(), int(value)), f"rt_set_option({name})")

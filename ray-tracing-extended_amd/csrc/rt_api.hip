@@ -50,6 +50,7 @@ struct rt_ctx {
     rt_params params{};
     bool have_params = false;
     int row0 = 0, nrows = -1;           // -1: whole image
+    int band_first = 0, band_stride = 0; // band_stride > 0: interleaved 8-row bands (overrides row0/nrows)
 
     std::vector<rt_sphere>   h_spheres;
     std::vector<rt_triangle> h_tris;
@@ -61,7 +62,7 @@ struct rt_ctx {
     DevBuf<uint32_t> d_raw_range;
     DevBuf<float4> d_frame, d_accum;
     size_t target_pixels = 0;
-    int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0;
+    int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0, target_row_stride = 8;
     unsigned int* d_tile_counter = nullptr;
     unsigned long long* d_counters = nullptr;
 
@@ -194,9 +195,14 @@ int build_scene(rt_ctx* c)
 int ensure_targets(rt_ctx* c)
 {
     const int W = c->params.width, H = c->params.height;
-    const int r0 = c->nrows < 0 ? 0 : c->row0, nr = c->nrows < 0 ? H : c->nrows;
-    if (r0 < 0 || nr < 0 || r0 + nr > H) return fail(c, -6, "row strip [%d,%d) outside image height %d", r0, r0 + nr, H);
-    if (W == c->target_w && H == c->target_h && r0 == c->target_row0 && nr == c->target_rows) return 0;
+    int r0 = c->nrows < 0 ? 0 : c->row0, nr = c->nrows < 0 ? H : c->nrows, rstride = 8;
+    if (c->band_stride > 0) {
+        // bands band_first, band_first + band_stride, ... of 8 rows each; the image's last band may be partial
+        r0 = c->band_first * 8; rstride = c->band_stride * 8; nr = 0;
+        for (int y = r0; y < H; y += rstride) nr += std::min(8, H - y);
+        if (r0 > H) r0 = H;
+    } else if (r0 < 0 || nr < 0 || r0 + nr > H) return fail(c, -6, "row strip [%d,%d) outside image height %d", r0, r0 + nr, H);
+    if (W == c->target_w && H == c->target_h && r0 == c->target_row0 && nr == c->target_rows && rstride == c->target_row_stride) return 0;
     const size_t px = (size_t)W * nr;
     RT_HIP(c, c->d_frame.ensure(px));
     RT_HIP(c, c->d_accum.ensure(px));
@@ -205,7 +211,7 @@ int ensure_targets(rt_ctx* c)
         RT_HIP(c, hipMemsetAsync(c->d_frame.p, 0, px * sizeof(float4), c->stream));
         RT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, px * sizeof(float4), c->stream));
     }
-    c->target_pixels = px; c->target_w = W; c->target_h = H; c->target_row0 = r0; c->target_rows = nr;
+    c->target_pixels = px; c->target_w = W; c->target_h = H; c->target_row0 = r0; c->target_rows = nr; c->target_row_stride = rstride;
     c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0;
     return 0;
 }
@@ -231,7 +237,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
 
     rtk::FrameArgs F{};
     F.p = c->params;
-    F.row0 = c->target_row0; F.nrows = c->target_rows;
+    F.row0 = c->target_row0; F.nrows = c->target_rows; F.row_stride = c->target_row_stride;
     F.tiles_x = (c->target_w + 7) / 8; F.tiles_y = (c->target_rows + 7) / 8;
     const bool stream = c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
     const bool pooled = c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
@@ -456,7 +462,15 @@ int rt_set_rows(rt_ctx* c, int row0, int nrows)
 {
     if (!c) return -1;
     if (row0 < 0 || nrows < 0) return fail(c, -2, "bad row strip (%d,%d)", row0, nrows);
-    c->row0 = row0; c->nrows = nrows;
+    c->row0 = row0; c->nrows = nrows; c->band_stride = 0;
+    return 0;
+}
+
+int rt_set_bands(rt_ctx* c, int first_band, int band_stride)
+{
+    if (!c) return -1;
+    if (first_band < 0 || band_stride < 1 || first_band >= band_stride) return fail(c, -2, "bad band pattern (%d,%d)", first_band, band_stride);
+    c->band_first = first_band; c->band_stride = band_stride;
     return 0;
 }
 

@@ -41,7 +41,8 @@ struct DeviceScene {
 struct FrameArgs {
     rt_params p;
     int frame;
-    int row0, nrows;            // strip of the full image rendered by this launch
+    int row0, nrows;            // rows rendered by this launch: local row ly -> global row row0 + (ly/8)*row_stride + ly%8
+    int row_stride;             // 8: one contiguous strip; 8*N: every N-th 8-row band (interleaved decomposition)
     int tiles_x, tiles_y;
     int stack_cap;              // LDS stack entries per lane
     int full_sort;              // 1: sort all four children of a node by distance, 0: nearest first only
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, 
         const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
         const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
         if (x < F.p.width && ly < F.nrows) {
-            const int y = F.row0 + ly;
+            const int y = F.row0 + ty * F.row_stride + (lane >> 3);
             v3 c = render_pixel<COUNT, FLAT>(S, F.p, F.full_sort != 0, F.frame, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[pi] = make_float4(c.x, c.y, c.z, 1.0f);                        // frag :388

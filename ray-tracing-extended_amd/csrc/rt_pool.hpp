@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                         const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (int)(within >> 3);
                         if (x < p.width && yy < F.nrows) {
                             px = x; ly = yy; pix = (uint32_t)yy * W + (uint32_t)x;
-                            rng = ((uint32_t)(F.row0 + yy) * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;   // :361-362
+                            rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;   // :361-362
                             sample = 0;
                             F.out_frame[pix] = make_float4(0.f, 0.f, 0.f, 0.f);       // running sum of the pixel's samples
                             st = PEND;      // "has a pixel" (the real state is written below)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                 if (have_pixel) {
                     // ---- next camera ray: frag :364-382
                     phase_tick<COUNT>(cnt, 4);
-                    const int y = F.row0 + ly;
+                    const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
                     const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                     const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
                     cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
             const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
             if (x < p.width && yy < F.nrows) {
                 px = x; ly = yy;
-                rng = ((uint32_t)(F.row0 + yy) * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;          // :361-362
+                rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;   // :361-362
                 total = rtm::mk(0.f, 0.f, 0.f);
                 sample = 0; live = false; fresh = true;
                 mode = kModeShade;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                             const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (int)(within >> 3);
                             if (x < p.width && yy < F.nrows) {
                                 px = x; ly = yy;
-                                const int y = F.row0 + yy;
+                                const int y = F.row0 + (yy >> 3) * F.row_stride + (yy & 7);
                                 rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;      // :361-362
                                 total = rtm::mk(0.f, 0.f, 0.f);
                                 sample = 0;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                     if (need_ray) {
                         // ---- frag :364-382
                         phase_tick<COUNT>(cnt, 4);
-                        const int y = F.row0 + ly;
+                        const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
                         const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
                         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,

@@ -33,3 +33,42 @@ def gather_image(strip, height: int, dist=None, dst: int = 0):
     if rank != dst:
         return None
     return torch.cat(bufs, dim=0)[:height]
+
+
+# ---- interleaved 8-row bands: same single gather, balanced load ---------------------------------------------------------
+BAND = 8
+
+
+def band_rows(height: int, world: int, rank: int):
+    """Global row indices rendered by `rank` when 8-row bands are dealt round-robin (band b -> rank b % world), in the
+    order the rank stores them.  Sky rows and object rows then spread evenly over the ranks."""
+    if world < 1 or not (0 <= rank < world) or height < 0:
+        raise ValueError(f"bad decomposition: height={height} world={world} rank={rank}")
+    rows = []
+    for y0 in range(rank * BAND, height, world * BAND):
+        rows.extend(range(y0, min(y0 + BAND, height)))
+    return rows
+
+
+def band_rows_padded(height: int, world: int) -> int:
+    """Rows every rank contributes to the gather (the largest per-rank row count)."""
+    return max((len(band_rows(height, world, r)) for r in range(world)), default=0)
+
+
+def gather_image_banded(strip, height: int, dist=None, dst: int = 0):
+    """strip: torch tensor [band_rows_padded, W, 4] holding this rank's bands back to back.  One gather; rank `dst`
+    scatters the gathered rows to their image positions and returns [height, W, 4], the others None."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return strip[:height]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bufs = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
+    dist.gather(strip, bufs, dst=dst)
+    if rank != dst:
+        return None
+    image = torch.empty((height,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
+    for r in range(world):
+        rows = band_rows(height, world, r)
+        if rows:
+            image[torch.as_tensor(rows, device=strip.device)] = bufs[r][:len(rows)]
+    return image

@@ -17,7 +17,19 @@ if rank == 0:
     full, _, _ = orc.render(*b, 0, 2)
     assert img.shape == (H, W, 4)
     assert np.array_equal(img.numpy().view(np.uint32), full.view(np.uint32)), "assembled image differs"
-    print("GLOO_OK")
+    print("GLOO_STRIPS_OK")
 else:
     assert img is None
+# ---- interleaved 8-row bands, same scene
+rows = rtx.distributed.band_rows(H, world, rank)
+per = rtx.distributed.band_rows_padded(H, world)
+full2, _, _ = orc.render(*b, 0, 2)           # every rank renders the full image here only to pick its rows from it
+strip = torch.zeros(per, W, 4)
+for i, y in enumerate(rows):
+    acc_row, _, _ = orc.render(*b, 0, 2, rect=(0, y, W, y + 1))
+    strip[i] = torch.from_numpy(acc_row[0])
+img = rtx.distributed.gather_image_banded(strip, H, dist)
+if rank == 0:
+    assert np.array_equal(img.numpy().view(np.uint32), full2.view(np.uint32)), "banded image differs"
+    print("GLOO_BANDS_OK")
 dist.destroy_process_group()

@@ -129,3 +129,23 @@ def test_pool_kernel_knobs_do_not_change_the_image(rtx, tracer, trav_min, pool_s
         tracer.set_option("pool_stack", 10)
     assert_bitwise(got_last, ref_last, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, last frame")
     assert_bitwise(got, ref, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, accum")
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_interleaved_bands_are_decomposition_invariant(rtx, tracer, kernel):
+    """8-row bands dealt round-robin to 3 'ranks' reassemble to the undivided image (61 rows: partial last band)."""
+    b = rtx.scenes.mesh_test_scene(80, 61).build_buffers()
+    full, _ = run_gpu(tracer, b, 0, 2, kernel=kernel)
+    out = np.zeros_like(full)
+    for rank in range(3):
+        rows = rtx.distributed.band_rows(61, 3, rank)
+        params, spheres, tris, infos = b
+        tracer.set_params(params)
+        tracer.set_bands(rank, 3)
+        tracer.reset_accum()
+        tracer.render(0, 2)
+        got = tracer.read_accum()
+        assert got.shape[0] == len(rows)
+        out[rows] = got
+    tracer.set_rows(0, 61)
+    assert_bitwise(out, full, "interleaved bands")

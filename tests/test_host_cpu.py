@@ -159,6 +159,19 @@ def test_row_strip_partition_properties(rtx):
         rs(10, 2, 2)
 
 
+def test_band_partition_properties(rtx):
+    D = rtx.distributed
+    for H in (0, 5, 8, 61, 1080, 2160):
+        for world in (1, 2, 3, 8):
+            allrows = sorted(r for k in range(world) for r in D.band_rows(H, world, k))
+            assert allrows == list(range(H))
+            assert D.band_rows_padded(H, world) == max(len(D.band_rows(H, world, k)) for k in range(world))
+    assert D.band_rows(20, 2, 1) == [8, 9, 10, 11, 12, 13, 14, 15]
+    assert rtx.distributed.band_rows(1080, 8, 7)[:9] == [56, 57, 58, 59, 60, 61, 62, 63, 120]
+    # 1080 rows over 8 ranks: 135 bands -> 17 or 16 bands per rank
+    assert sorted({len(D.band_rows(1080, 8, k)) for k in range(8)}) == [128, 136]
+
+
 def test_two_rank_gloo_strips_assemble_to_the_full_image():
     """world_size 2 over gloo: every rank renders its strip (the CPU oracle stands in for the GPU kernel here), one gather,
     rank 0 compares with the undivided image bit for bit."""
@@ -168,4 +181,4 @@ def test_two_rank_gloo_strips_assemble_to_the_full_image():
                         os.path.join(ROOT, "tests", "gloo_strip_worker.py")],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "GLOO_OK" in r.stdout
+    assert "GLOO_STRIPS_OK" in r.stdout and "GLOO_BANDS_OK" in r.stdout
