@@ -351,3 +351,99 @@ class RayTracingManager:
         self.backend.render(self.numRenderedFrames, frames)
         self.numRenderedFrames += frames
         return self.backend.read_accum()
+
+
+# ---- MeshSplitter (Assets/Scripts/Helpers/MeshSplitter.cs) ----------------------------------------------------------------
+class _UBounds:
+    """UnityEngine.Bounds in float32: stored as centre + extents (Bounds.cs of the public UnityCsReference):
+    Bounds(c, size): extents = size*0.5; size = extents*2; min/max = centre -/+ extents;
+    SetMinMax(mn, mx): extents = (mx-mn)*0.5, centre = mn + extents; Encapsulate(p) = SetMinMax(Min(min,p), Max(max,p));
+    Contains(p): p >= centre-extents and p <= centre+extents on every axis (native AABB::IsInside — unpinned)."""
+    __slots__ = ("center", "extents")
+
+    def __init__(self, center, size):
+        self.center = np.asarray(center, np.float32).copy()
+        self.extents = (np.asarray(size, np.float32) * f32(0.5)).astype(np.float32)
+
+    @property
+    def size(self):
+        return (self.extents * f32(2)).astype(np.float32)
+
+    @property
+    def min(self):
+        return (self.center - self.extents).astype(np.float32)
+
+    @property
+    def max(self):
+        return (self.center + self.extents).astype(np.float32)
+
+    def set_min_max(self, mn, mx):
+        self.extents = ((mx - mn) * f32(0.5)).astype(np.float32)
+        self.center = (mn + self.extents).astype(np.float32)
+
+    def encapsulate_points(self, pts):
+        """Encapsulate a sequence of points one after the other (order matters in float32: centre/extents are re-derived
+        after every point)."""
+        for p in np.asarray(pts, np.float32).reshape(-1, 3):
+            self.set_min_max(np.minimum(self.min, p), np.maximum(self.max, p))
+
+    def contains(self, pts):
+        pts = np.asarray(pts, np.float32)
+        return np.all((pts >= self.min) & (pts <= self.max), axis=-1)
+
+
+class MeshSplitter:
+    """Restatement of MeshSplitter.cs:8-124: recursive 8-octant split until <= 48 triangles or depth 6; a triangle goes
+    to the first octant (x, then y, then z loop order) that contains any of its vertices."""
+    maxDepth = 6                # MeshSplitter.cs:8
+    maxTrisPerChunk = 48        # MeshSplitter.cs:9
+
+    @staticmethod
+    def CreateSubMesh(triangles: np.ndarray, subMeshIndex: int, firstVertex=None) -> MeshChunk:
+        """:35-63 — bounds start as a box of size 0.01 at the first vertex, then every vertex is encapsulated in order.
+        `triangles` is the sub-mesh's triangle list (TRIANGLE[n]) in index-buffer order."""
+        v0 = triangles["posA"][0] if firstVertex is None else firstVertex
+        b = _UBounds(v0, np.full(3, 0.01, np.float32))
+        pts = np.stack([triangles["posA"], triangles["posB"], triangles["posC"]], axis=1).reshape(-1, 3)
+        b.encapsulate_points(pts)
+        return MeshChunk(triangles.copy(), b, subMeshIndex)
+
+    @staticmethod
+    def CreateChunks(sub_meshes) -> list:
+        """:11-33 — `sub_meshes` = [(TRIANGLE[n], subMeshIndex)] in sub-mesh order."""
+        out = []
+        for tris, idx in sub_meshes:
+            MeshSplitter.Split(MeshSplitter.CreateSubMesh(tris, idx), out)
+        return out
+
+    @staticmethod
+    def Split(chunk: MeshChunk, out: list, depth: int = 0):
+        """:65-99"""
+        tris = chunk.triangles
+        if len(tris) > MeshSplitter.maxTrisPerChunk and depth < MeshSplitter.maxDepth:
+            b = chunk.bounds
+            q = (b.size / f32(4)).astype(np.float32)
+            taken = np.zeros(len(tris), bool)
+            for x in (-1, 1):
+                for y in (-1, 1):
+                    for z in (-1, 1):
+                        if len(tris) - int(taken.sum()) > 0:
+                            off = np.array([q[0] * f32(x), q[1] * f32(y), q[2] * f32(z)], np.float32)
+                            split = _UBounds((b.center + off).astype(np.float32), (q * f32(2)).astype(np.float32))
+                            sub = MeshSplitter.Extract(tris, taken, split, chunk.subMeshIndex)
+                            if len(sub.triangles) > 0:
+                                MeshSplitter.Split(sub, out, depth + 1)
+        else:
+            out.append(chunk)
+
+    @staticmethod
+    def Extract(tris: np.ndarray, taken: np.ndarray, split: "_UBounds", subMeshIndex: int) -> MeshChunk:
+        """:101-124"""
+        inside = split.contains(tris["posA"]) | split.contains(tris["posB"]) | split.contains(tris["posC"])
+        pick = inside & ~taken
+        new_bounds = _UBounds(split.center, split.size)
+        sel = tris[pick]
+        pts = np.stack([sel["posA"], sel["posB"], sel["posC"]], axis=1).reshape(-1, 3)
+        new_bounds.encapsulate_points(pts)
+        taken |= pick
+        return MeshChunk(sel.copy(), new_bounds, subMeshIndex)
