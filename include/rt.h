@@ -58,6 +58,24 @@ typedef struct rt_meshinfo {            /* 96 B */
     float       boundsMax[3];
 } rt_meshinfo;
 
+/* ---- on-device geometry pipeline (optional) -----------------------------------------------------------------
+ * The reference transforms every mesh to world space on the CPU and re-uploads the scene every frame
+ * (RayTracedMesh.cs:36-84, RayTracingManager.cs:135-164; TODO at RayTracedMesh.cs:37).  With these two layouts the
+ * local-space chunks are uploaded once and a frame only sends one transform per mesh.                       */
+typedef struct rt_mesh_transform {      /* 40 B: transform.position / rotation (x,y,z,w) / lossyScale (RayTracedMesh.cs:38-40) */
+    float position[3];
+    float rotation[4];
+    float lossyScale[3];
+} rt_mesh_transform;
+
+typedef struct rt_local_chunk {         /* 80 B: one MeshChunk of RayTracedMesh.localChunks (MeshChunk.cs:6-17) */
+    uint32_t    firstTriangleIndex;     /* into the local triangle buffer                                        */
+    uint32_t    numTriangles;
+    uint32_t    meshIndex;              /* which rt_mesh_transform moves it                                      */
+    uint32_t    _reserved;
+    rt_material material;               /* RayTracedMesh.GetMaterial(chunk.subMeshIndex), RayTracedMesh.cs:96-99 */
+} rt_local_chunk;
+
 /* ---- uniforms ------------------------------------------------------------------------------------
  * One POD holding exactly what RayTracingManager pushes with Material.Set{Int,Float,Vector,Matrix,Color}
  * (RayTracingManager.cs:113-123,131-132) plus the three Unity built-ins the shader reads
@@ -109,6 +127,7 @@ typedef struct rt_stats {
                                         /* lane utilisation of phase k = phaseLanes[k] / (64*phaseExecs[k])  */
     double   lastKernelMs;              /* HIP-event time of the last trace(+accumulate) launch          */
     double   totalKernelMs;             /* sum over launches since rt_reset_accum                        */
+    double   lastGeometryMs;            /* HIP-event time of the last on-device transform + bounds + re-layout + refit */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -135,6 +154,17 @@ int rt_set_params(rt_ctx* ctx, const rt_params* params);
 int rt_upload_spheres  (rt_ctx* ctx, const rt_sphere*   spheres,  int n);
 int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris,     int n);
 int rt_upload_meshinfo (rt_ctx* ctx, const rt_meshinfo* meshinfo, int n);
+
+/* On-device geometry pipeline.  rt_upload_local_meshes replaces rt_upload_triangles + rt_upload_meshinfo: local-space
+ * triangles (reference layout, 72 B) and their chunks; rt_set_mesh_transforms sends the n_meshes poses.  The library
+ * transforms to world space on the GPU (rot * Scale(p, lossyScale) + pos; normals rot * n — RayTracedMesh.cs:86-94),
+ * recomputes the chunks' world AABBs (:74-82), and refits its BVH; the image is bit-identical to uploading the
+ * host-transformed buffers.  rt_read_world_geometry returns what the reference's CreateMeshes would have uploaded
+ * (n_tris rt_triangle, n_chunks rt_meshinfo).                                                                  */
+int rt_upload_local_meshes(rt_ctx* ctx, const rt_triangle* local_tris, int n_tris,
+                           const rt_local_chunk* chunks, int n_chunks, int n_meshes);
+int rt_set_mesh_transforms(rt_ctx* ctx, const rt_mesh_transform* transforms, int n_meshes);
+int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_meshinfo* meshinfo_out, int n_chunks);
 
 /* Tuning knobs; the image never depends on them (tested bitwise).
  *   "kernel"          0 = tile-per-wave megakernel k_trace (default), 1 = k_stream (resumable traversal, stragglers
@@ -183,7 +213,7 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 
 /* ABI self-description for binding generators / tests. */
 int rt_abi_version(void);
-int rt_sizeof(const char* struct_name);   /* "rt_material" | "rt_sphere" | "rt_triangle" | "rt_meshinfo" | "rt_params" | "rt_stats" */
+int rt_sizeof(const char* struct_name);   /* "rt_material" | "rt_sphere" | "rt_triangle" | "rt_meshinfo" | "rt_params" | "rt_stats" | "rt_mesh_transform" | "rt_local_chunk" */
 
 #ifdef __cplusplus
 }

@@ -39,8 +39,11 @@ STATS = np.dtype([
     ("numBvhNodes", "<i4"), ("bvhMaxStack", "<i4"),
     ("rays", "<u8"), ("sphereTests", "<u8"), ("nodeVisits", "<u8"), ("triTests", "<u8"), ("hits", "<u8"),
     ("phaseLanes", "<u8", 5), ("phaseExecs", "<u8", 5),
-    ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"),
+    ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"), ("lastGeometryMs", "<f8"),
 ])
+MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])
+LOCAL_CHUNK = np.dtype([("firstTriangleIndex", "<u4"), ("numTriangles", "<u4"), ("meshIndex", "<u4"), ("_reserved", "<u4"),
+                        ("material", MATERIAL)])
 assert MATERIAL.itemsize == 64 and SPHERE.itemsize == 80 and TRIANGLE.itemsize == 72 and MESHINFO.itemsize == 96
 
 RT_INTERSECT_FLAT_CHUNKS = 0
@@ -51,7 +54,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_params", "rt_upload_spheres",
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
-    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands",
+    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry",
 ]
 
 _lib = None
@@ -83,6 +86,9 @@ def load_library() -> ctypes.CDLL:
     lib.rt_set_rows.argtypes = [c_void_p, c_int, c_int]
     lib.rt_set_option.argtypes = [c_void_p, c_char_p, c_int]
     lib.rt_set_bands.argtypes = [c_void_p, c_int, c_int]
+    lib.rt_upload_local_meshes.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int]
+    lib.rt_set_mesh_transforms.argtypes = [c_void_p, c_void_p, c_int]
+    lib.rt_read_world_geometry.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int]
     lib.rt_render_frame.argtypes = [c_void_p, c_int]
     lib.rt_render_frame_flat.argtypes = [c_void_p, c_int]
     lib.rt_render.argtypes = [c_void_p, c_int, c_int]
@@ -100,7 +106,8 @@ def load_library() -> ctypes.CDLL:
             continue
         f.restype = c_int
     for name, dt in (("rt_material", MATERIAL), ("rt_sphere", SPHERE), ("rt_triangle", TRIANGLE),
-                     ("rt_meshinfo", MESHINFO), ("rt_params", PARAMS), ("rt_stats", STATS)):
+                     ("rt_meshinfo", MESHINFO), ("rt_params", PARAMS), ("rt_stats", STATS),
+                     ("rt_mesh_transform", MESH_TRANSFORM), ("rt_local_chunk", LOCAL_CHUNK)):
         got = lib.rt_sizeof(name.encode())
         if got != dt.itemsize:
             raise RtError(f"ABI mismatch: sizeof({name}) = {got} in the library, {dt.itemsize} in the binding")
@@ -160,6 +167,24 @@ class Tracer:
         if meshinfo is not None:
             a, ptr, n = _as_buffer(meshinfo, MESHINFO)
             self._check(self._lib.rt_upload_meshinfo(self._ctx, ptr, n), "rt_upload_meshinfo")
+
+    # -- on-device geometry pipeline
+    def upload_local_meshes(self, local_tris, chunks, n_meshes: int):
+        t, tp, nt = _as_buffer(local_tris, TRIANGLE)
+        ch, cp, nc = _as_buffer(chunks, LOCAL_CHUNK)
+        self._local_counts = (nt, nc)
+        self._check(self._lib.rt_upload_local_meshes(self._ctx, tp, nt, cp, nc, int(n_meshes)), "rt_upload_local_meshes")
+
+    def set_mesh_transforms(self, transforms):
+        x, xp, n = _as_buffer(transforms, MESH_TRANSFORM)
+        self._check(self._lib.rt_set_mesh_transforms(self._ctx, xp, n), "rt_set_mesh_transforms")
+
+    def read_world_geometry(self):
+        nt, nc = self._local_counts
+        tris, infos = np.zeros(nt, TRIANGLE), np.zeros(nc, MESHINFO)
+        self._check(self._lib.rt_read_world_geometry(self._ctx, tris.ctypes.data_as(c_void_p), nt,
+                                                     infos.ctypes.data_as(c_void_p), nc), "rt_read_world_geometry")
+        return tris, infos
 
     def set_rows(self, row0: int, nrows: int):
         self._rows = (row0, nrows)

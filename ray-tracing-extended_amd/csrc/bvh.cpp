@@ -128,7 +128,7 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 
 void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out)
 {
-    out.nodes.clear(); out.order.clear(); out.maxStack = 0; out.depth = 0;
+    out.nodes.clear(); out.order.clear(); out.maxStack = 0; out.depth = 0; out.levelStart.clear();
     if (n_tris == 0) return;
 
     Builder B; B.pos = tri_pos; B.stride = stride_floats; B.n = n_tris;
@@ -152,7 +152,7 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
     out.depth = B.depth;
 
     // ---- collapse to 4-wide, breadth-first ----
-    struct Pending { int bnode; uint32_t slot; };
+    struct Pending { int bnode; uint32_t slot; int level; };
     std::vector<Node4>& N = out.nodes;
     std::queue<Pending> q;
     auto new_node = [&]() -> uint32_t {
@@ -166,9 +166,11 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
         N.push_back(z);
         return (uint32_t)N.size() - 1u;
     };
-    q.push({ root, new_node() });
+    q.push({ root, new_node(), 0 });
+    out.levelStart.push_back(0);
     while (!q.empty()) {
         Pending pd = q.front(); q.pop();
+        if ((int)out.levelStart.size() <= pd.level) out.levelStart.push_back(pd.slot);
         int kids[4]; int nk = 0;
         const BNode& r = B.bn[pd.bnode];
         if (r.count > 0) { kids[nk++] = pd.bnode; }         // the whole mesh fits one leaf
@@ -191,7 +193,7 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
             pad_box(c.box, G, mn, mx);
             uint32_t ref;
             if (c.count > 0) ref = make_leaf(c.first, c.count);
-            else { ref = new_node(); q.push({ kids[k], ref }); }
+            else { ref = new_node(); q.push({ kids[k], ref, pd.level + 1 }); }
             Node4& me = N[pd.slot];                          // (re-fetch: new_node may reallocate)
             me.minx[k] = mn[0]; me.miny[k] = mn[1]; me.minz[k] = mn[2];
             me.maxx[k] = mx[0]; me.maxy[k] = mx[1]; me.maxz[k] = mx[2];
@@ -199,6 +201,8 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
         }
         N[pd.slot].meta[0] = (uint32_t)nk;
     }
+
+    out.levelStart.push_back((uint32_t)N.size());
 
     // ---- worst-case traversal stack: at a node with k used slots the nearest child becomes current and up
     // to k-1 are pushed; nodes are in BFS order so children have larger indices -> sweep backwards.

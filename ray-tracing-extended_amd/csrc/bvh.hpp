@@ -33,6 +33,7 @@ struct Bvh {
     int                   maxStack = 0; // worst-case number of entries the traversal stack can hold
     int                   depth = 0;
     float                 magnitude = 0.f;  // G used for the box padding (scene coordinates and ray origins)
+    std::vector<uint32_t> levelStart;       // nodes of tree level L are [levelStart[L], levelStart[L+1]) (breadth-first order)
 };
 
 // tri_pos: 9 floats per triangle (posA, posB, posC).  origin_magnitude = largest |coordinate| a ray origin outside

@@ -15,6 +15,7 @@
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
 #include "rt_pool.hpp"
+#include "rt_geom.hpp"
 
 namespace {
 
@@ -56,6 +57,17 @@ struct rt_ctx {
     std::vector<rt_triangle> h_tris;
     std::vector<rt_meshinfo> h_mesh;
     bool scene_dirty = true;
+    // on-device geometry pipeline (rt_upload_local_meshes / rt_set_mesh_transforms)
+    bool geom_local = false, xf_dirty = false;
+    std::vector<rt_triangle>       h_local_tris;
+    std::vector<rt_local_chunk>    h_lchunks;
+    std::vector<rt_mesh_transform> h_xf;
+    std::vector<float>             mesh_radius;     // largest |local coordinate| * sqrt(3) per mesh
+    int n_meshes = 0;
+    DevBuf<float> d_local_tris;
+    DevBuf<uint32_t> d_tri_mesh, d_tri_chunk, d_order;
+    DevBuf<rtg::MeshXf> d_xf;
+    hipEvent_t evg0 = nullptr, evg1 = nullptr;
 
     DevBuf<float4> d_sph_geom, d_sph_mat, d_nodes, d_tri_geo, d_tri_nrm, d_chunk_mat, d_chunk_box;
     DevBuf<float>  d_raw_tris;
@@ -192,6 +204,122 @@ int build_scene(rt_ctx* c)
     return 0;
 }
 
+// ---- on-device geometry pipeline -------------------------------------------------------------------------------
+// Conservative bound of |coordinate| over camera-ray origins and the transformed meshes (box padding, bvh.cpp pad_box).
+float local_scene_magnitude(const rt_ctx* c)
+{
+    float G = camera_magnitude(c->params);
+    for (int m = 0; m < c->n_meshes; ++m) {
+        const rt_mesh_transform& t = c->h_xf[m];
+        float p = std::max(std::fabs(t.position[0]), std::max(std::fabs(t.position[1]), std::fabs(t.position[2])));
+        float sc = std::max(std::fabs(t.lossyScale[0]), std::max(std::fabs(t.lossyScale[1]), std::fabs(t.lossyScale[2])));
+        G = std::max(G, p + 1.01f * sc * c->mesh_radius[m]);
+    }
+    return G;
+}
+
+int upload_spheres_and_materials(rt_ctx* c)
+{
+    const size_t ns = c->h_spheres.size();
+    std::vector<float4> sg(ns), sm(4 * ns);
+    for (size_t i = 0; i < ns; ++i) {
+        const rt_sphere& s = c->h_spheres[i];
+        sg[i] = make_float4(s.position[0], s.position[1], s.position[2], s.radius);
+        pack_material(s.material, &sm[4 * i]);
+    }
+    RT_HIP(c, c->d_sph_geom.ensure(ns)); RT_HIP(c, c->d_sph_mat.ensure(4 * ns));
+    if (ns) {
+        RT_HIP(c, hipMemcpyAsync(c->d_sph_geom.p, sg.data(), ns * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync(c->d_sph_mat.p, sm.data(), 4 * ns * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.numSpheres = (int)ns;
+    return 0;
+}
+
+// transform + chunk bounds (+ re-layout and refit when the BVH topology already exists)
+int run_geometry_kernels(rt_ctx* c, bool have_bvh)
+{
+    const uint32_t nt = (uint32_t)c->h_local_tris.size(), nm = (uint32_t)c->h_lchunks.size();
+    std::vector<rtg::MeshXf> xf(c->n_meshes);
+    for (int m = 0; m < c->n_meshes; ++m) {
+        const rt_mesh_transform& t = c->h_xf[m];
+        xf[m] = { t.position[0], t.position[1], t.position[2], t.rotation[0], t.rotation[1], t.rotation[2], t.rotation[3],
+                  t.lossyScale[0], t.lossyScale[1], t.lossyScale[2] };
+    }
+    RT_HIP(c, c->d_xf.ensure(xf.size()));
+    if (!xf.empty()) RT_HIP(c, hipMemcpyAsync(c->d_xf.p, xf.data(), xf.size() * sizeof(rtg::MeshXf), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipEventRecord(c->evg0, c->stream));
+    if (nt) {
+        hipLaunchKernelGGL(rtg::k_transform, dim3((nt + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_local_tris.p, c->d_tri_mesh.p, c->d_xf.p, c->d_raw_tris.p, nt);
+        hipLaunchKernelGGL(rtg::k_chunk_bounds, dim3((nm + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_raw_tris.p, c->d_raw_range.p, c->d_chunk_box.p, nm);
+    }
+    if (have_bvh && nt) {
+        hipLaunchKernelGGL(rtg::k_relayout, dim3((nt + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_geo.p, c->d_tri_nrm.p, nt);
+        const float G = std::max(c->bvh.magnitude, local_scene_magnitude(c));
+        c->bvh.magnitude = G;
+        for (int L = (int)c->bvh.levelStart.size() - 2; L >= 0; --L) {
+            const uint32_t n0 = c->bvh.levelStart[L], n1 = c->bvh.levelStart[L + 1];
+            if (n1 > n0)
+                hipLaunchKernelGGL(rtg::k_refit_level, dim3(((n1 - n0) * 4 + 255) / 256), dim3(256), 0, c->stream,
+                                   reinterpret_cast<rtbvh::Node4*>(c->d_nodes.p), n0, n1, c->d_raw_tris.p, c->d_order.p, G);
+        }
+    }
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipEventRecord(c->evg1, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
+    c->stats.lastGeometryMs = ms;
+    return 0;
+}
+
+int build_scene_local(rt_ctx* c)
+{
+    const size_t nt = c->h_local_tris.size(), nm = c->h_lchunks.size();
+    if ((int)c->h_xf.size() != c->n_meshes) return fail(c, -2, "rt_set_mesh_transforms has not been called for the %d meshes", c->n_meshes);
+    { int r = upload_spheres_and_materials(c); if (r) return r; }
+    std::vector<uint32_t> tri_mesh(nt), tri_chunk(nt), range(2 * nm);
+    std::vector<float4> cm(4 * nm);
+    for (size_t m = 0; m < nm; ++m) {
+        const rt_local_chunk& ch = c->h_lchunks[m];
+        for (uint32_t i = 0; i < ch.numTriangles; ++i) { tri_mesh[ch.firstTriangleIndex + i] = ch.meshIndex; tri_chunk[ch.firstTriangleIndex + i] = (uint32_t)m; }
+        range[2 * m] = ch.firstTriangleIndex; range[2 * m + 1] = ch.numTriangles;
+        pack_material(ch.material, &cm[4 * m]);
+    }
+#define RT_UP(buf, vec, T)                                                                                  \
+    RT_HIP(c, buf.ensure(vec.size()));                                                                      \
+    if (!vec.empty()) RT_HIP(c, hipMemcpyAsync(buf.p, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    RT_UP(c->d_tri_mesh, tri_mesh, uint32_t) RT_UP(c->d_tri_chunk, tri_chunk, uint32_t)
+    RT_UP(c->d_raw_range, range, uint32_t) RT_UP(c->d_chunk_mat, cm, float4)
+#undef RT_UP
+    RT_HIP(c, c->d_local_tris.ensure(nt * 18)); RT_HIP(c, c->d_raw_tris.ensure(nt * 18));
+    RT_HIP(c, c->d_chunk_box.ensure(2 * nm)); RT_HIP(c, c->d_tri_geo.ensure(3 * nt)); RT_HIP(c, c->d_tri_nrm.ensure(3 * nt));
+    if (nt) RT_HIP(c, hipMemcpyAsync(c->d_local_tris.p, c->h_local_tris.data(), nt * sizeof(rt_triangle), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    // world positions (device) -> host, for the one-off topology build
+    { int r = run_geometry_kernels(c, false); if (r) return r; }
+    std::vector<rt_triangle> world(nt);
+    if (nt) RT_HIP(c, hipMemcpy(world.data(), c->d_raw_tris.p, nt * sizeof(rt_triangle), hipMemcpyDeviceToHost));
+    rtbvh::build(nt ? world[0].posA : nullptr, 18, (uint32_t)nt, local_scene_magnitude(c), c->opt_max_leaf, c->bvh);
+    RT_HIP(c, c->d_nodes.ensure(c->bvh.nodes.size() * 8)); RT_HIP(c, c->d_order.ensure(nt));
+    if (!c->bvh.nodes.empty()) {
+        RT_HIP(c, hipMemcpyAsync(c->d_nodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node4), hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync(c->d_order.p, c->bvh.order.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(rtg::k_relayout, dim3(((uint32_t)nt + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_geo.p, c->d_tri_nrm.p, (uint32_t)nt);
+        RT_HIP(c, hipGetLastError());
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
+    c->stats.numBvhNodes = (int)c->bvh.nodes.size(); c->stats.bvhMaxStack = c->bvh.maxStack;
+    c->scene_dirty = false; c->xf_dirty = false;
+    return 0;
+}
+
 int ensure_targets(rt_ctx* c)
 {
     const int W = c->params.width, H = c->params.height;
@@ -224,8 +352,13 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
     if (n_frames < 0) return fail(c, -2, "n_frames < 0");
     RT_HIP(c, hipSetDevice(c->device));
-    if (!c->scene_dirty && camera_magnitude(c->params) > c->bvh.magnitude) c->scene_dirty = true;   // re-pad the boxes
-    if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
+    if (c->geom_local) {
+        if (c->scene_dirty) { int r = build_scene_local(c); if (r) return r; }
+        else if (c->xf_dirty || local_scene_magnitude(c) > c->bvh.magnitude) { int r = run_geometry_kernels(c, true); if (r) return r; c->xf_dirty = false; }
+    } else {
+        if (!c->scene_dirty && camera_magnitude(c->params) > c->bvh.magnitude) c->scene_dirty = true;   // re-pad the boxes
+        if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
+    }
     { int r = ensure_targets(c); if (r) return r; }
     if (c->target_pixels == 0 || n_frames == 0) return 0;
 
@@ -233,7 +366,9 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     S.sph_geom = c->d_sph_geom.p; S.sph_mat = c->d_sph_mat.p; S.nodes = c->d_nodes.p;
     S.tri_geo = c->d_tri_geo.p; S.tri_nrm = c->d_tri_nrm.p; S.chunk_mat = c->d_chunk_mat.p; S.chunk_box = c->d_chunk_box.p;
     S.raw_tris = c->d_raw_tris.p; S.raw_chunk_range = c->d_raw_range.p;
-    S.ns = (int)c->h_spheres.size(); S.nn = (int)c->bvh.nodes.size(); S.nt = (int)c->h_tris.size(); S.nm = (int)c->h_mesh.size();
+    S.ns = (int)c->h_spheres.size(); S.nn = (int)c->bvh.nodes.size();
+    S.nt = c->geom_local ? (int)c->h_local_tris.size() : (int)c->h_tris.size();
+    S.nm = c->geom_local ? (int)c->h_lchunks.size() : (int)c->h_mesh.size();
 
     rtk::FrameArgs F{};
     F.p = c->params;
@@ -355,6 +490,8 @@ int rt_sizeof(const char* name)
     if (!std::strcmp(name, "rt_meshinfo")) return (int)sizeof(rt_meshinfo);
     if (!std::strcmp(name, "rt_params"))   return (int)sizeof(rt_params);
     if (!std::strcmp(name, "rt_stats"))    return (int)sizeof(rt_stats);
+    if (!std::strcmp(name, "rt_mesh_transform")) return (int)sizeof(rt_mesh_transform);
+    if (!std::strcmp(name, "rt_local_chunk")) return (int)sizeof(rt_local_chunk);
     return -1;
 }
 
@@ -374,6 +511,7 @@ rt_ctx* rt_create(int device)
     c->n_cu = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess
         || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess
+        || (e = hipEventCreate(&c->evg0)) != hipSuccess || (e = hipEventCreate(&c->evg1)) != hipSuccess
         || (e = hipMalloc((void**)&c->d_tile_counter, sizeof(unsigned int))) != hipSuccess
         || (e = hipMalloc((void**)&c->d_counters, rtk::kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
         fail(nullptr, -1, "context setup: %s", hipGetErrorString(e));
@@ -396,6 +534,9 @@ void rt_destroy(rt_ctx* c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evg0) (void)hipEventDestroy(c->evg0);
+    if (c->evg1) (void)hipEventDestroy(c->evg1);
+    c->d_local_tris.release(); c->d_tri_mesh.release(); c->d_tri_chunk.release(); c->d_order.release(); c->d_xf.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -430,14 +571,73 @@ int rt_upload_triangles(rt_ctx* c, const rt_triangle* t, int n)
 {
     if (!c) return -1;
     if (n < 0 || (n > 0 && !t)) return fail(c, -2, "bad triangle upload (n=%d)", n);
-    c->h_tris.assign(t, t + n); c->scene_dirty = true;
+    c->h_tris.assign(t, t + n); c->scene_dirty = true; c->geom_local = false;
     return 0;
 }
 int rt_upload_meshinfo(rt_ctx* c, const rt_meshinfo* m, int n)
 {
     if (!c) return -1;
     if (n < 0 || (n > 0 && !m)) return fail(c, -2, "bad meshinfo upload (n=%d)", n);
-    c->h_mesh.assign(m, m + n); c->scene_dirty = true;
+    c->h_mesh.assign(m, m + n); c->scene_dirty = true; c->geom_local = false;
+    return 0;
+}
+
+int rt_upload_local_meshes(rt_ctx* c, const rt_triangle* tris, int n_tris, const rt_local_chunk* chunks, int n_chunks, int n_meshes)
+{
+    if (!c) return -1;
+    if (n_tris < 0 || n_chunks < 0 || n_meshes < 0 || (n_tris > 0 && !tris) || (n_chunks > 0 && !chunks)) return fail(c, -2, "bad local mesh upload");
+    if (n_tris > (1 << 28)) return fail(c, -3, "too many triangles (%d)", n_tris);
+    std::vector<uint8_t> seen(n_tris, 0);
+    std::vector<float> radius(n_meshes, 0.f);
+    for (int m = 0; m < n_chunks; ++m) {
+        const rt_local_chunk& ch = chunks[m];
+        if ((uint64_t)ch.firstTriangleIndex + ch.numTriangles > (uint64_t)n_tris) return fail(c, -4, "chunk %d addresses triangles beyond the %d uploaded", m, n_tris);
+        if (ch.meshIndex >= (uint32_t)n_meshes) return fail(c, -4, "chunk %d refers to mesh %u of %d", m, ch.meshIndex, n_meshes);
+        for (uint32_t i = 0; i < ch.numTriangles; ++i) {
+            uint8_t& s = seen[ch.firstTriangleIndex + i];
+            if (s) return fail(c, -5, "triangle %u is referenced by more than one chunk", ch.firstTriangleIndex + i);
+            s = 1;
+            const float* p = tris[ch.firstTriangleIndex + i].posA;
+            for (int k = 0; k < 9; ++k) radius[ch.meshIndex] = std::max(radius[ch.meshIndex], std::fabs(p[k]));
+        }
+    }
+    for (int t = 0; t < n_tris; ++t) if (!seen[t]) return fail(c, -5, "triangle %d belongs to no chunk", t);
+    for (float& r : radius) r *= 1.7320508f;
+    c->h_local_tris.assign(tris, tris + n_tris); c->h_lchunks.assign(chunks, chunks + n_chunks);
+    c->mesh_radius = radius; c->n_meshes = n_meshes;
+    c->geom_local = true; c->scene_dirty = true;
+    return 0;
+}
+
+int rt_set_mesh_transforms(rt_ctx* c, const rt_mesh_transform* xf, int n_meshes)
+{
+    if (!c) return -1;
+    if (n_meshes < 0 || (n_meshes > 0 && !xf)) return fail(c, -2, "bad transform upload");
+    if (c->geom_local && n_meshes != c->n_meshes) return fail(c, -2, "%d transforms for %d meshes", n_meshes, c->n_meshes);
+    c->h_xf.assign(xf, xf + n_meshes);
+    c->xf_dirty = true;
+    return 0;
+}
+
+int rt_read_world_geometry(rt_ctx* c, rt_triangle* tris_out, int n_tris, rt_meshinfo* mi_out, int n_chunks)
+{
+    if (!c) return -1;
+    if (!c->geom_local) return fail(c, -2, "no local meshes uploaded");
+    if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
+    if (n_tris != (int)c->h_local_tris.size() || n_chunks != (int)c->h_lchunks.size()) return fail(c, -2, "size mismatch");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (c->scene_dirty) { int r = build_scene_local(c); if (r) return r; }
+    else if (c->xf_dirty) { int r = run_geometry_kernels(c, true); if (r) return r; c->xf_dirty = false; }
+    if (n_tris) RT_HIP(c, hipMemcpy(tris_out, c->d_raw_tris.p, (size_t)n_tris * sizeof(rt_triangle), hipMemcpyDeviceToHost));
+    std::vector<float4> box(2 * (size_t)n_chunks);
+    if (n_chunks) RT_HIP(c, hipMemcpy(box.data(), c->d_chunk_box.p, box.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int m = 0; m < n_chunks; ++m) {
+        const rt_local_chunk& ch = c->h_lchunks[m];
+        rt_meshinfo& mi = mi_out[m];
+        mi.firstTriangleIndex = ch.firstTriangleIndex; mi.numTriangles = ch.numTriangles; mi.material = ch.material;
+        mi.boundsMin[0] = box[2 * m].x; mi.boundsMin[1] = box[2 * m].y; mi.boundsMin[2] = box[2 * m].z;
+        mi.boundsMax[0] = box[2 * m + 1].x; mi.boundsMax[1] = box[2 * m + 1].y; mi.boundsMax[2] = box[2 * m + 1].z;
+    }
     return 0;
 }
 

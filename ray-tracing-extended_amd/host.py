@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from ._cabi import MATERIAL, MESHINFO, PARAMS, SPHERE, TRIANGLE, RT_INTERSECT_FLAT_CHUNKS
+from ._cabi import LOCAL_CHUNK, MATERIAL, MESH_TRANSFORM, MESHINFO, PARAMS, SPHERE, TRIANGLE, RT_INTERSECT_FLAT_CHUNKS
 
 f32 = np.float32
 
@@ -253,6 +253,7 @@ class RayTracingManager:
         self.linearColourSpace = linearColourSpace        # ProjectSettings.asset:50 (m_ActiveColorSpace: 1)
         self.intersectMode = RT_INTERSECT_FLAT_CHUNKS
         self.backend = backend
+        self.deviceGeometry = False                       # True: transform / bounds / BVH refit on the GPU (rt_upload_local_meshes)
         self._dirty = True
 
     # -- RayTracingManager.cs:196-203
@@ -320,6 +321,30 @@ class RayTracingManager:
         all_info = np.array(infos, dtype=MESHINFO) if infos else np.zeros(0, MESHINFO)
         return all_tris, all_info
 
+    # -- the same scene for the on-device geometry pipeline: local chunks once, one transform per mesh per frame
+    def build_local_buffers(self):
+        tris, chunks = [], []
+        count = 0
+        for mi, mesh in enumerate(self.meshes):
+            if mesh.enforceTriangleLimit and mesh.triangleCount > RayTracingManager.TriangleLimit:
+                raise Exception(f"Please use a mesh with fewer than {RayTracingManager.TriangleLimit} triangles")
+            for chunk in mesh.localChunks:
+                c = np.zeros((), LOCAL_CHUNK)
+                c["firstTriangleIndex"], c["numTriangles"], c["meshIndex"] = count, len(chunk.triangles), mi
+                c["material"] = mesh.GetMaterial(chunk.subMeshIndex).pack()
+                chunks.append(c)
+                tris.append(chunk.triangles)
+                count += len(chunk.triangles)
+        self.numMeshChunks, self.numTriangles = len(chunks), count
+        return (np.concatenate(tris) if tris else np.zeros(0, TRIANGLE),
+                np.array(chunks, dtype=LOCAL_CHUNK) if chunks else np.zeros(0, LOCAL_CHUNK))
+
+    def build_transforms(self) -> np.ndarray:
+        xf = np.zeros(len(self.meshes), MESH_TRANSFORM)
+        for i, mesh in enumerate(self.meshes):
+            xf[i]["position"], xf[i]["rotation"], xf[i]["lossyScale"] = mesh.transform.position, mesh.transform.rotation, mesh.transform.lossyScale
+        return xf
+
     def build_buffers(self):
         """InitFrame (RayTracingManager.cs:95-109) without the device: params + the three structured buffers."""
         params = np.zeros((), PARAMS)
@@ -334,6 +359,19 @@ class RayTracingManager:
     def InitFrame(self):
         if self.backend is None:
             raise RuntimeError("RayTracingManager has no backend (HIP Tracer); there is no CPU path")
+        if self.deviceGeometry:
+            params = np.zeros((), PARAMS)
+            params["width"], params["height"] = self.width, self.height
+            params["intersectMode"] = self.intersectMode
+            self.UpdateCameraParams(params)
+            self.SetShaderParams(params)
+            self.backend.set_params(params)
+            if self._dirty:                                  # geometry: once
+                self.backend.upload(spheres=self.CreateSpheres())
+                self.backend.upload_local_meshes(*self.build_local_buffers(), len(self.meshes))
+                self._dirty = False
+            self.backend.set_mesh_transforms(self.build_transforms())    # poses: every frame (40 B per mesh)
+            return
         params, spheres, tris, infos = self.build_buffers()
         self.backend.set_params(params)
         if self._dirty:
