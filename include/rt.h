@@ -128,6 +128,7 @@ typedef struct rt_stats {
     double   lastKernelMs;              /* HIP-event time of the last trace(+accumulate) launch          */
     double   totalKernelMs;             /* sum over launches since rt_reset_accum                        */
     double   lastGeometryMs;            /* HIP-event time of the last on-device transform + bounds + re-layout + refit */
+    double   lastDisplayMs;             /* HIP-event time of the last linear -> sRGB8 display kernel     */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -208,6 +209,11 @@ int rt_read_accum     (rt_ctx* ctx, float* rgba, size_t n_floats);
 int rt_read_last_frame(rt_ctx* ctx, float* rgba, size_t n_floats);
 /* Device-side copy of the strip into caller-owned device memory (e.g. a torch tensor handed to RCCL). */
 int rt_copy_accum_to_device(rt_ctx* ctx, void* dst_device_ptr, size_t n_floats);
+
+/* Display step after the path: resultTexture converted linear -> sRGB, 8 bits per channel (R | G<<8 | B<<16 | A<<24),
+ * as the final Blit(resultTexture, target) into the sRGB back buffer does (RayTracingManager.cs:84;
+ * ProjectSettings.asset:50).  n_pixels = rows*width of this context's strip; row 0 is the bottom row.             */
+int rt_read_display(rt_ctx* ctx, uint32_t* rgba8, size_t n_pixels);
 
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 

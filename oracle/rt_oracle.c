@@ -473,6 +473,25 @@ void orc_accumulate(float* accum, const float* cur, size_t n_floats, int frame)
         accum[i] = om_saturate(accum[i] * omw + cur[i] * weight);
 }
 
+/* Display step after the path: the reference's final Blit(resultTexture, target) (RayTracingManager.cs:84) writes the
+ * linear RGBA32F result into an sRGB 8-bit back buffer (Linear colour space project, ProjectSettings.asset:50).  Frozen:
+ * c' = c <= 0.0031308 ? 12.92*c : 1.055*pow(c, 1/2.4) - 0.055 with the frozen pow above; v = (uint8)floor(sat(c')*255 + 0.5);
+ * alpha is stored linearly.  Output pixel = R | G << 8 | B << 16 | A << 24. */
+static inline uint32_t to_unorm8(float v) { return (uint32_t)floorf(om_saturate(v) * 255.0f + 0.5f); }
+static inline float linear_to_srgb(float c)
+{
+    c = om_saturate(c);
+    return (c <= 0.0031308f) ? 12.92f * c : 1.055f * om_pow(c, 0.41666666f) - 0.055f;
+}
+void orc_display_srgb8(const float* rgba, uint32_t* out, size_t n_pixels)
+{
+    for (size_t i = 0; i < n_pixels; i++) {
+        const float* p = rgba + 4 * i;
+        out[i] = to_unorm8(linear_to_srgb(p[0])) | (to_unorm8(linear_to_srgb(p[1])) << 8)
+               | (to_unorm8(linear_to_srgb(p[2])) << 16) | (to_unorm8(p[3]) << 24);
+    }
+}
+
 int orc_hw_threads(void)
 {
 #ifdef _OPENMP

@@ -34,6 +34,9 @@ int orc_render_frame(const rt_params* params,
 /* Accumulate.shader:43-54 applied in place to `accum` (n_floats = pixels*4). */
 void orc_accumulate(float* accum, const float* cur, size_t n_floats, int frame);
 
+/* linear RGBA32F -> sRGB RGBA8 (the display blit after the path, RayTracingManager.cs:84) */
+void orc_display_srgb8(const float* rgba, uint32_t* out, size_t n_pixels);
+
 /* pieces exported for known-answer tests */
 uint32_t orc_next_random(uint32_t* state);
 float    orc_random_value(uint32_t* state);

@@ -10,7 +10,7 @@ module `rtx_amd`.  Only what the hot path needs lives here:
     unity_scene.py  loader for the reference's .unity scenes + compact scene interchange format
     distributed.py  row-strip decomposition + frame-end gather
 """
-from . import _cabi, distributed, host, scenes, unity_scene  # noqa: F401
+from . import _cabi, distributed, host, imageio, scenes, unity_scene  # noqa: F401
 from ._cabi import (LOCAL_CHUNK, MATERIAL, MESH_TRANSFORM, MESHINFO, PARAMS, SPHERE, STATS, TRIANGLE, RT_INTERSECT_BRUTE,  # noqa: F401
                     RT_INTERSECT_FLAT_CHUNKS, RtError, Tracer, load_library)
 from .host import (Camera, EnvironmentSettings, Light, MaterialFlag, MeshChunk, RayTracedMesh,  # noqa: F401

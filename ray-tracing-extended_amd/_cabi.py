@@ -39,7 +39,7 @@ STATS = np.dtype([
     ("numBvhNodes", "<i4"), ("bvhMaxStack", "<i4"),
     ("rays", "<u8"), ("sphereTests", "<u8"), ("nodeVisits", "<u8"), ("triTests", "<u8"), ("hits", "<u8"),
     ("phaseLanes", "<u8", 5), ("phaseExecs", "<u8", 5),
-    ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"), ("lastGeometryMs", "<f8"),
+    ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"), ("lastGeometryMs", "<f8"), ("lastDisplayMs", "<f8"),
 ])
 MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])
 LOCAL_CHUNK = np.dtype([("firstTriangleIndex", "<u4"), ("numTriangles", "<u4"), ("meshIndex", "<u4"), ("_reserved", "<u4"),
@@ -54,7 +54,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_params", "rt_upload_spheres",
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
-    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry",
+    "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry", "rt_read_display",
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def load_library() -> ctypes.CDLL:
     lib.rt_read_last_frame.argtypes = [c_void_p, POINTER(c_float), c_size_t]
     lib.rt_copy_accum_to_device.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.rt_get_stats.argtypes = [c_void_p, c_void_p]
+    lib.rt_read_display.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.rt_abi_version.restype = c_int
     lib.rt_sizeof.argtypes = [c_char_p]
     for n in SYMBOLS:
@@ -234,6 +235,13 @@ class Tracer:
         out = np.empty((rows, W, 4), np.float32)
         self._check(self._lib.rt_read_last_frame(self._ctx, out.ctypes.data_as(POINTER(c_float)), out.size), "rt_read_last_frame")
         return out
+
+    def read_display(self) -> np.ndarray:
+        """resultTexture as sRGB RGBA8, shape (rows, W, 4) uint8, row 0 = bottom."""
+        rows, W = self._strip_shape()
+        out = np.empty((rows, W), np.uint32)
+        self._check(self._lib.rt_read_display(self._ctx, out.ctypes.data_as(c_void_p), out.size), "rt_read_display")
+        return out.view(np.uint8).reshape(rows, W, 4)
 
     def copy_accum_to_device(self, device_ptr: int, n_floats: int):
         self._check(self._lib.rt_copy_accum_to_device(self._ctx, c_void_p(device_ptr), n_floats), "rt_copy_accum_to_device")

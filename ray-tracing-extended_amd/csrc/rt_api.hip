@@ -73,6 +73,7 @@ struct rt_ctx {
     DevBuf<float>  d_raw_tris;
     DevBuf<uint32_t> d_raw_range;
     DevBuf<float4> d_frame, d_accum;
+    DevBuf<uint32_t> d_display;
     size_t target_pixels = 0;
     int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0, target_row_stride = 8;
     unsigned int* d_tile_counter = nullptr;
@@ -529,7 +530,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_display.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -695,6 +696,28 @@ int rt_reset_accum(rt_ctx* c)
 int rt_read_accum(rt_ctx* c, float* rgba, size_t n) { return read_target(c, true, rgba, n, false); }
 int rt_read_last_frame(rt_ctx* c, float* rgba, size_t n) { return read_target(c, false, rgba, n, false); }
 int rt_copy_accum_to_device(rt_ctx* c, void* dst, size_t n) { return read_target(c, true, (float*)dst, n, true); }
+
+int rt_read_display(rt_ctx* c, uint32_t* rgba8, size_t n_pixels)
+{
+    if (!c) return -1;
+    if (!rgba8 && n_pixels) return fail(c, -2, "null destination");
+    if (c->have_params) { int r = ensure_targets(c); if (r) return r; }
+    if (n_pixels != c->target_pixels) return fail(c, -2, "expected %zu pixels (rows*width), got %zu", c->target_pixels, n_pixels);
+    if (!n_pixels) return 0;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, c->d_display.ensure(n_pixels));
+    RT_HIP(c, hipEventRecord(c->evg0, c->stream));
+    const int grid = (int)std::min<size_t>((n_pixels + 255) / 256, (size_t)c->n_cu * 8);
+    hipLaunchKernelGGL(rtg::k_display_srgb8, dim3(grid), dim3(256), 0, c->stream, c->d_accum.p, c->d_display.p, n_pixels);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipEventRecord(c->evg1, c->stream));
+    RT_HIP(c, hipMemcpyAsync(rgba8, c->d_display.p, n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
+    c->stats.lastDisplayMs = ms;
+    return 0;
+}
 
 int rt_get_stats(rt_ctx* c, rt_stats* out)
 {

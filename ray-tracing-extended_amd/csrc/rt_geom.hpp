@@ -136,4 +136,22 @@ __global__ __launch_bounds__(256) void k_refit_level(rtbvh::Node4* __restrict__ 
     N.maxx[k] = mx[0]; N.maxy[k] = mx[1]; N.maxz[k] = mx[2];
 }
 
+// ---- display step after the path: linear RGBA32F -> sRGB RGBA8 (the reference's final Blit(resultTexture, target) into an
+// sRGB back buffer, RayTracingManager.cs:84, ProjectSettings.asset:50).  16 B read + 4 B write per pixel.
+__device__ __forceinline__ float linear_to_srgb(float c)
+{
+    c = rtm::saturate(c);
+    return (c <= 0.0031308f) ? 12.92f * c : 1.055f * rtm::pow_(c, 0.41666666f) - 0.055f;
+}
+__device__ __forceinline__ uint32_t to_unorm8(float v) { return (uint32_t)__builtin_floorf(rtm::saturate(v) * 255.0f + 0.5f); }
+
+__global__ __launch_bounds__(256) void k_display_srgb8(const float4* __restrict__ rgba, uint32_t* __restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 p = rgba[i];
+        out[i] = to_unorm8(linear_to_srgb(p.x)) | (to_unorm8(linear_to_srgb(p.y)) << 8)
+               | (to_unorm8(linear_to_srgb(p.z)) << 16) | (to_unorm8(p.w) << 24);
+    }
+}
+
 } // namespace rtg

@@ -43,6 +43,8 @@ class Oracle:
         for n in ("om_pow", "om_min", "om_max"):
             getattr(L, n).restype = c_float
             getattr(L, n).argtypes = [c_float, c_float]
+        L.orc_display_srgb8.restype = None
+        L.orc_display_srgb8.argtypes = [POINTER(c_float), c_void_p, c_size_t]
         L.orc_hw_threads.restype = c_int
 
     def render_frame(self, params, spheres, tris, meshinfo, frame, rect=None, mode=None, nthreads=0):
@@ -69,6 +71,12 @@ class Oracle:
     def accumulate(self, accum, cur, frame):
         assert accum.dtype == np.float32 and cur.dtype == np.float32 and accum.flags.c_contiguous and cur.flags.c_contiguous
         self.lib.orc_accumulate(accum.ctypes.data_as(POINTER(c_float)), cur.ctypes.data_as(POINTER(c_float)), accum.size, frame)
+
+    def display_srgb8(self, rgba):
+        a = np.ascontiguousarray(rgba, np.float32)
+        out = np.empty(a.shape[:-1], np.uint32)
+        self.lib.orc_display_srgb8(a.ctypes.data_as(POINTER(c_float)), out.ctypes.data_as(c_void_p), out.size)
+        return out.view(np.uint8).reshape(a.shape[:-1] + (4,))
 
     def render(self, params, spheres, tris, meshinfo, first_frame, n_frames, rect=None, mode=None):
         """Trace + accumulate n_frames frames (OnRenderImage order); returns (accum, last_frame, counts)."""

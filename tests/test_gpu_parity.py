@@ -149,3 +149,17 @@ def test_interleaved_bands_are_decomposition_invariant(rtx, tracer, kernel):
         out[rows] = got
     tracer.set_rows(0, 61)
     assert_bitwise(out, full, "interleaved bands")
+
+
+def test_display_srgb8_matches_oracle(rtx, oracle, tracer, tmp_path):
+    """Display step after the path (linear -> sRGB8, RayTracingManager.cs:84): GPU kernel == oracle on every byte."""
+    b = rtx.scenes.config1(160, 96).build_buffers()
+    acc, _ = run_gpu(tracer, b, 0, 2)
+    got = tracer.read_display()
+    want = oracle.display_srgb8(acc)
+    assert got.shape == (96, 160, 4) and got.dtype == np.uint8
+    assert np.array_equal(got, want), f"{int((got != want).any(-1).sum())} pixels differ"
+    assert got[..., 3].min() == 255 and got[..., :3].max() == 255 and got[..., :3].min() < 40
+    rtx.imageio.write_png(str(tmp_path / "c1.png"), got)
+    rtx.imageio.write_pfm(str(tmp_path / "c1.pfm"), acc)
+    assert (tmp_path / "c1.png").stat().st_size > 1000

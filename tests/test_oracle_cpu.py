@@ -129,3 +129,12 @@ def test_flat_chunks_vs_brute_on_reference_scene(rtx, oracle):
     differing = int(((flat.view(np.uint32) != brute.view(np.uint32)) & ~(np.isnan(flat) & np.isnan(brute))).any(-1).sum())
     assert differing <= 2, differing
     assert cf["boxTests"] == 39 * cf["rays"] and cb["boxTests"] == 0 and cb["triTests"] == 530 * cb["rays"]
+
+
+def test_display_srgb8_known_values(oracle):
+    """sRGB transfer: 0 -> 0, 1 -> 255, 0.0031308 -> 10 (linear segment), 0.5 -> 188, 0.2159 -> 128; >1 and NaN clamp."""
+    px = np.array([[0.0, 1.0, 0.0031308, 1.0], [0.5, 0.2159, 2.0, 0.5], [np.nan, -1.0, 0.05, 1.0]], np.float32)
+    out = oracle.display_srgb8(px[None])[0]
+    assert out[0].tolist() == [0, 255, 10, 255]
+    assert out[1].tolist() == [188, 128, 255, 128]
+    assert out[2].tolist() == [0, 0, 63, 255]
