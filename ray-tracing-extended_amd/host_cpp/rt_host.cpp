@@ -1,0 +1,214 @@
+// rt_host.cpp — C++ host components (see rt_host.hpp).  Arithmetic mirrors host.py operation for operation.
+#include "rt_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rthost {
+
+Vector3 operator*(const Quaternion& q, const Vector3& p)
+{
+    const float x = q.x, y = q.y, z = q.z, w = q.w;
+    const float x2 = x * 2.0f, y2 = y * 2.0f, z2 = z * 2.0f;
+    const float xx = x * x2, yy = y * y2, zz = z * z2;
+    const float xy = x * y2, xz = x * z2, yz = y * z2;
+    const float wx = w * x2, wy = w * y2, wz = w * z2;
+    Vector3 r;
+    r.x = ((1.0f - (yy + zz)) * p.x + (xy - wz) * p.y) + (xz + wy) * p.z;
+    r.y = ((xy + wz) * p.x + (1.0f - (xx + zz)) * p.y) + (yz - wx) * p.z;
+    r.z = ((xz - wy) * p.x + (yz + wx) * p.y) + (1.0f - (xx + yy)) * p.z;
+    return r;
+}
+
+Quaternion operator*(const Quaternion& a, const Quaternion& b)
+{
+    Quaternion r;
+    r.x = ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y;
+    r.y = ((a.w * b.y + a.y * b.w) + a.z * b.x) - a.x * b.z;
+    r.z = ((a.w * b.z + a.z * b.w) + a.x * b.y) - a.y * b.x;
+    r.w = ((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z;
+    return r;
+}
+
+void Transform::localToWorldMatrix(float m[16]) const
+{
+    const float x = rotation.x, y = rotation.y, z = rotation.z, w = rotation.w;
+    const float r[3][3] = {
+        { 1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - z * w), 2.0f * (x * z + y * w) },
+        { 2.0f * (x * y + z * w), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - x * w) },
+        { 2.0f * (x * z - y * w), 2.0f * (y * z + x * w), 1.0f - 2.0f * (x * x + y * y) } };
+    const float s[3] = { lossyScale.x, lossyScale.y, lossyScale.z };
+    const float t[3] = { position.x, position.y, position.z };
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) m[4 * i + j] = r[i][j] * s[j];
+        m[4 * i + 3] = t[i];
+    }
+    m[12] = m[13] = m[14] = 0.0f; m[15] = 1.0f;
+}
+
+Vector3 Light::worldSpaceLightPos0() const
+{
+    Vector3 f = rotation * Vector3{ 0, 0, 1 };
+    return { -f.x, -f.y, -f.z };
+}
+
+std::vector<MeshChunk> RayTracedMesh::GetSubMeshes() const
+{
+    if (enforceTriangleLimit && triangleCount > RayTracingManager::TriangleLimit)
+        throw std::runtime_error("Please use a mesh with fewer than " + std::to_string(RayTracingManager::TriangleLimit) + " triangles");
+    std::vector<MeshChunk> world(localChunks.size());
+    const Vector3 pos = transform.position, scale = transform.lossyScale;
+    const Quaternion rot = transform.rotation;
+    for (size_t c = 0; c < localChunks.size(); ++c) {                            // UpdateWorldChunkFromLocal :56-84
+        const MeshChunk& lc = localChunks[c];
+        MeshChunk& wc = world[c];
+        wc.triangles.resize(lc.triangles.size());
+        wc.subMeshIndex = lc.subMeshIndex;
+        float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t i = 0; i < lc.triangles.size(); ++i) {
+            const float* s = lc.triangles[i].posA;
+            float* d = wc.triangles[i].posA;
+            for (int k = 0; k < 3; ++k) {                                        // PointLocalToWorld :86-89
+                Vector3 r = rot * Vector3{ s[3 * k] * scale.x, s[3 * k + 1] * scale.y, s[3 * k + 2] * scale.z };
+                d[3 * k] = r.x + pos.x; d[3 * k + 1] = r.y + pos.y; d[3 * k + 2] = r.z + pos.z;
+                for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], d[3 * k + a]); mx[a] = std::max(mx[a], d[3 * k + a]); }
+            }
+            for (int k = 3; k < 6; ++k) {                                        // DirectionLocalToWorld :91-94
+                Vector3 r = rot * Vector3{ s[3 * k], s[3 * k + 1], s[3 * k + 2] };
+                d[3 * k] = r.x; d[3 * k + 1] = r.y; d[3 * k + 2] = r.z;
+            }
+        }
+        wc.bounds.center = { (mn[0] + mx[0]) / 2.0f, (mn[1] + mx[1]) / 2.0f, (mn[2] + mx[2]) / 2.0f };   // :82
+        wc.bounds.size = { mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2] };
+    }
+    return world;
+}
+
+const RayTracingMaterial& RayTracedMesh::GetMaterial(int subMeshIndex) const
+{
+    return materials[std::min<size_t>((size_t)std::max(subMeshIndex, 0), materials.size() - 1)];
+}
+
+void RayTracingManager::OnValidate()
+{
+    maxBounceCount = std::max(0, maxBounceCount);
+    numRaysPerPixel = std::max(1, numRaysPerPixel);
+    environmentSettings.sunFocus = std::max(1.0, environmentSettings.sunFocus);
+    environmentSettings.sunIntensity = std::max(0.0, environmentSettings.sunIntensity);
+}
+
+void RayTracingManager::UpdateCameraParams(rt_params& p) const
+{
+    const float deg2rad = 0.017453292f;
+    const float half = (float)camera.fieldOfView * 0.5f * deg2rad;
+    const float planeHeight = (float)focusDistance * (float)std::tan((double)half) * 2.0f;
+    const float planeWidth = planeHeight * (float)camera.aspect;
+    p.viewParams[0] = planeWidth; p.viewParams[1] = planeHeight; p.viewParams[2] = (float)focusDistance;
+    camera.transform.localToWorldMatrix(p.camLocalToWorld);
+    p.worldSpaceCameraPos[0] = camera.transform.position.x; p.worldSpaceCameraPos[1] = camera.transform.position.y;
+    p.worldSpaceCameraPos[2] = camera.transform.position.z;
+    const Vector3 l = light.worldSpaceLightPos0();
+    p.worldSpaceLightPos0[0] = l.x; p.worldSpaceLightPos0[1] = l.y; p.worldSpaceLightPos0[2] = l.z;
+}
+
+static double gamma_to_linear(double c)
+{
+    if (c <= 0.04045) return c / 12.92;
+    if (c < 1.0) return std::pow((c + 0.055) / 1.055, 2.4);
+    return std::pow(c, 2.2);
+}
+
+void RayTracingManager::SetShaderParams(rt_params& p) const
+{
+    p.maxBounceCount = maxBounceCount; p.numRaysPerPixel = numRaysPerPixel;
+    p.defocusStrength = (float)defocusStrength; p.divergeStrength = (float)divergeStrength;
+    const EnvironmentSettings& e = environmentSettings;
+    p.environmentEnabled = e.enabled ? 1 : 0;
+    const double* src[3] = { e.groundColour, e.skyColourHorizon, e.skyColourZenith };
+    float* dst[3] = { p.groundColour, p.skyColourHorizon, p.skyColourZenith };
+    for (int k = 0; k < 3; ++k) {
+        for (int ch = 0; ch < 3; ++ch) dst[k][ch] = (float)(linearColourSpace ? gamma_to_linear(src[k][ch]) : src[k][ch]);
+        dst[k][3] = (float)src[k][3];
+    }
+    p.sunFocus = (float)e.sunFocus; p.sunIntensity = (float)e.sunIntensity;
+}
+
+std::vector<rt_sphere> RayTracingManager::CreateSpheres() const
+{
+    std::vector<rt_sphere> out(spheres.size());
+    for (size_t i = 0; i < spheres.size(); ++i) {
+        const RayTracedSphere& s = spheres[i];
+        out[i].position[0] = s.transform.position.x; out[i].position[1] = s.transform.position.y; out[i].position[2] = s.transform.position.z;
+        out[i].radius = s.transform.localScale.x * 0.5f;                         // :178
+        out[i].material = s.material;
+    }
+    return out;
+}
+
+void RayTracingManager::CreateMeshes(std::vector<rt_triangle>& tris, std::vector<rt_meshinfo>& infos)
+{
+    tris.clear(); infos.clear();
+    for (const RayTracedMesh& mesh : meshes) {
+        for (const MeshChunk& chunk : mesh.GetSubMeshes()) {
+            rt_meshinfo mi{};
+            mi.firstTriangleIndex = (uint32_t)tris.size(); mi.numTriangles = (uint32_t)chunk.triangles.size();
+            mi.material = mesh.GetMaterial(chunk.subMeshIndex);
+            const Vector3 lo = chunk.bounds.min(), hi = chunk.bounds.max();      // MeshInfo.cs:16-17
+            mi.boundsMin[0] = lo.x; mi.boundsMin[1] = lo.y; mi.boundsMin[2] = lo.z;
+            mi.boundsMax[0] = hi.x; mi.boundsMax[1] = hi.y; mi.boundsMax[2] = hi.z;
+            infos.push_back(mi);
+            tris.insert(tris.end(), chunk.triangles.begin(), chunk.triangles.end());
+        }
+    }
+    numMeshChunks = (int)infos.size(); numTriangles = (int)tris.size();
+}
+
+SceneBuffers RayTracingManager::BuildBuffers()
+{
+    SceneBuffers b;
+    std::memset(&b.params, 0, sizeof b.params);
+    b.params.width = width; b.params.height = height;
+    b.params.intersectMode = intersectMode; b.params.rngMode = RT_RNG_PCG;
+    UpdateCameraParams(b.params);
+    b.spheres = CreateSpheres();
+    CreateMeshes(b.triangles, b.meshInfo);
+    SetShaderParams(b.params);
+    return b;
+}
+
+static void check(rt_ctx* ctx, int rc, const char* what)
+{
+    if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + rt_last_error(ctx));
+}
+
+void RayTracingManager::InitFrame(rt_ctx* ctx)
+{
+    SceneBuffers b = BuildBuffers();
+    check(ctx, rt_set_params(ctx, &b.params), "rt_set_params");
+    if (!uploaded_) {       // the reference re-uploads every frame (its TODO at RayTracedMesh.cs:37); once is enough here
+        check(ctx, rt_upload_spheres(ctx, b.spheres.data(), (int)b.spheres.size()), "rt_upload_spheres");
+        check(ctx, rt_upload_triangles(ctx, b.triangles.data(), (int)b.triangles.size()), "rt_upload_triangles");
+        check(ctx, rt_upload_meshinfo(ctx, b.meshInfo.data(), (int)b.meshInfo.size()), "rt_upload_meshinfo");
+        uploaded_ = true;
+    }
+}
+
+void RayTracingManager::Start(rt_ctx* ctx)
+{
+    numRenderedFrames = 0;
+    check(ctx, rt_reset_accum(ctx), "rt_reset_accum");
+}
+
+void RayTracingManager::OnRenderImage(rt_ctx* ctx, int frames, std::vector<float>* resultTexture)
+{
+    InitFrame(ctx);
+    check(ctx, rt_render(ctx, numRenderedFrames, frames), "rt_render");
+    numRenderedFrames += frames;
+    if (resultTexture) {
+        resultTexture->resize((size_t)width * height * 4);
+        check(ctx, rt_read_accum(ctx, resultTexture->data(), resultTexture->size()), "rt_read_accum");
+    }
+}
+
+} // namespace rthost

@@ -1,0 +1,65 @@
+"""ctypes window onto the compiled host (host_cpp/: C++ mirror of the reference's C# components + .unity loader)."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_void_p
+
+import numpy as np
+
+from ._cabi import MESHINFO, PARAMS, SPHERE, TRIANGLE, RtError
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_host.so")
+_lib = None
+
+
+def load_host_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError(f"{LIB_PATH} not found: run __graft_entry__.build()")
+        L = ctypes.CDLL(LIB_PATH)
+        L.rth_load_unity.restype = c_void_p
+        L.rth_load_unity.argtypes = [c_char_p, c_int, c_int]
+        L.rth_last_error.restype = c_char_p
+        L.rth_free.argtypes = [c_void_p]
+        L.rth_build.argtypes = [c_void_p, POINTER(c_int)]
+        L.rth_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.rth_render.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
+        _lib = L
+    return _lib
+
+
+class CppScene:
+    """A reference scene loaded and marshalled by the C++ host."""
+
+    def __init__(self, unity_path: str, width: int, height: int):
+        self._L = load_host_library()
+        self.width, self.height = width, height
+        self._h = self._L.rth_load_unity(unity_path.encode(), width, height)
+        if not self._h:
+            raise RtError("LoadUnityScene: " + self._L.rth_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.rth_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def build_buffers(self):
+        counts = (c_int * 7)()
+        if self._L.rth_build(self._h, counts):
+            raise RtError("BuildBuffers: " + self._L.rth_last_error().decode())
+        self.counts = dict(zip(("spheres", "triangles", "chunks", "meshes", "serialisedChunks", "serialisedTriangles", "maxBounceCount"), counts))
+        params = np.zeros((), PARAMS)
+        spheres, tris, infos = np.zeros(counts[0], SPHERE), np.zeros(counts[1], TRIANGLE), np.zeros(counts[2], MESHINFO)
+        self._L.rth_copy(self._h, params.ctypes.data_as(c_void_p), spheres.ctypes.data_as(c_void_p),
+                         tris.ctypes.data_as(c_void_p), infos.ctypes.data_as(c_void_p))
+        return params, spheres, tris, infos
+
+    def render(self, frames: int, device: int = 0) -> np.ndarray:
+        """RayTracingManager::Start + OnRenderImage(frames) on a fresh rt_ctx; returns resultTexture [H, W, 4]."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        if self._L.rth_render(self._h, device, frames, out.ctypes.data_as(POINTER(c_float))):
+            raise RtError("OnRenderImage: " + self._L.rth_last_error().decode())
+        return out

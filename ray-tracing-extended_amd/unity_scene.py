@@ -269,3 +269,84 @@ def load_scene_npz(path: str, width: int = 1920, height: int = 1080, backend=Non
         mgr.meshes.append(RayTracedMesh(Transform(position=pose[0:3], rotation=pose[3:7], lossyScale=pose[7:10]),
                                         [_row_mat(r) for r in z["mesh_mat"][m0:m0 + mn]], chunks, triangleCount=int(tc)))
     return mgr
+
+
+# ---- writer: a RayTracingManager as a minimal Unity-YAML scene (the subset the loaders read) ---------------------------
+def save_unity_scene(mgr: RayTracingManager, path: str):
+    """Writes plain scene objects (no prefab instances): one GameObject + Transform per component, world poses as local
+    poses of root objects.  Floats are written with repr() of the float32 value's shortest round-trip decimal."""
+    def f(v):
+        return repr(float(np.float32(v))) if not isinstance(v, float) else repr(v)
+
+    def v3(n, v):
+        return f"  {n}: {{x: {f(v[0])}, y: {f(v[1])}, z: {f(v[2])}}}"
+
+    def col(c):
+        c = list(c) + [1.0] * (4 - len(c))
+        return "{r: %s, g: %s, b: %s, a: %s}" % tuple(repr(float(x)) for x in c)
+
+    def mat_lines(m, ind):
+        p = " " * ind
+        return [f"{p}colour: {col(m.colour)}", f"{p}emissionColour: {col(m.emissionColour)}", f"{p}specularColour: {col(m.specularColour)}",
+                f"{p}emissionStrength: {repr(float(m.emissionStrength))}", f"{p}smoothness: {repr(float(m.smoothness))}",
+                f"{p}specularProbability: {repr(float(m.specularProbability))}", f"{p}flag: {int(m.flag)}"]
+
+    out = ["%YAML 1.1", "%TAG !u! tag:unity3d.com,2011:"]
+    next_id = [1000]
+
+    def game_object(name, tr, local_scale=None):
+        go, t = next_id[0], next_id[0] + 1
+        next_id[0] += 10
+        sc = tr.lossyScale if local_scale is None else local_scale
+        out.extend([f"--- !u!1 &{go}", "GameObject:", f"  m_Name: {name}", "  m_IsActive: 1",
+                    f"--- !u!4 &{t}", "Transform:", f"  m_GameObject: {{fileID: {go}}}",
+                    "  m_LocalRotation: {x: %s, y: %s, z: %s, w: %s}" % tuple(f(c) for c in tr.rotation),
+                    v3("m_LocalPosition", tr.position), v3("m_LocalScale", sc), "  m_Father: {fileID: 0}"])
+        return go
+
+    cam_go = game_object("Main Camera", mgr.camera.transform)
+    e = mgr.environmentSettings
+    out.extend([f"--- !u!114 &{next_id[0]}", "MonoBehaviour:", f"  m_GameObject: {{fileID: {cam_go}}}",
+                f"  m_Script: {{fileID: 11500000, guid: {GUID_MANAGER}, type: 3}}",
+                f"  maxBounceCount: {int(mgr.maxBounceCount)}", f"  numRaysPerPixel: {int(mgr.numRaysPerPixel)}",
+                f"  defocusStrength: {repr(float(mgr.defocusStrength))}", f"  divergeStrength: {repr(float(mgr.divergeStrength))}",
+                f"  focusDistance: {repr(float(mgr.focusDistance))}", "  environmentSettings:",
+                f"    enabled: {1 if e.enabled else 0}", f"    groundColour: {col(e.groundColour)}",
+                f"    skyColourHorizon: {col(e.skyColourHorizon)}", f"    skyColourZenith: {col(e.skyColourZenith)}",
+                f"    sunFocus: {repr(float(e.sunFocus))}", f"    sunIntensity: {repr(float(e.sunIntensity))}",
+                f"  numMeshChunks: {sum(len(m.localChunks) for m in mgr.meshes)}",
+                f"  numTriangles: {sum(len(c.triangles) for m in mgr.meshes for c in m.localChunks)}"])
+    next_id[0] += 10
+    out.extend([f"--- !u!20 &{next_id[0]}", "Camera:", f"  m_GameObject: {{fileID: {cam_go}}}", f"  field of view: {repr(float(mgr.camera.fieldOfView))}"])
+    next_id[0] += 10
+    light_go = game_object("Directional Light", Transform(rotation=mgr.light.rotation))
+    out.extend([f"--- !u!108 &{next_id[0]}", "Light:", f"  m_GameObject: {{fileID: {light_go}}}", "  m_Type: 1"])
+    next_id[0] += 10
+    for i, s in enumerate(mgr.spheres):
+        go = game_object(f"Sphere ({i})", s.transform, s.transform.localScale)
+        out.extend([f"--- !u!114 &{next_id[0]}", "MonoBehaviour:", f"  m_GameObject: {{fileID: {go}}}",
+                    f"  m_Script: {{fileID: 11500000, guid: {GUID_SPHERE}, type: 3}}", "  material:"] + mat_lines(s.material, 4))
+        next_id[0] += 10
+    for i, m in enumerate(mgr.meshes):
+        go = game_object(f"Mesh ({i})", m.transform)
+        out.extend([f"--- !u!114 &{next_id[0]}", "MonoBehaviour:", f"  m_GameObject: {{fileID: {go}}}",
+                    f"  m_Script: {{fileID: 11500000, guid: {GUID_MESH}, type: 3}}", "  materials:"])
+        for mat in m.materials:
+            ml = mat_lines(mat, 4)
+            out.append("  - " + ml[0].strip())
+            out.extend(ml[1:])
+        out.extend([f"  triangleCount: {int(m.triangleCount)}", "  localChunks:"])
+        for c in m.localChunks:
+            out.append("  - triangles:")
+            for t in c.triangles:
+                first = True
+                for k in TRIANGLE.names:
+                    v = t[k]
+                    out.append(("    - " if first else "      ") + f"{k}: {{x: {f(v[0])}, y: {f(v[1])}, z: {f(v[2])}}}")
+                    first = False
+            ext = (np.asarray(c.bounds.size, np.float32) * np.float32(0.5)).astype(np.float32)
+            out.extend(["    bounds:", "    " + v3("m_Center", c.bounds.center).strip().join(["  ", ""]),
+                        "    " + v3("m_Extent", ext).strip().join(["  ", ""]), f"    subMeshIndex: {int(c.subMeshIndex)}"])
+        next_id[0] += 10
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")

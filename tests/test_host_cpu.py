@@ -182,3 +182,43 @@ def test_two_rank_gloo_strips_assemble_to_the_full_image():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GLOO_STRIPS_OK" in r.stdout and "GLOO_BANDS_OK" in r.stdout
+
+
+def test_cpp_host_marshals_the_same_bytes_as_the_python_host(rtx, tmp_path):
+    """Compiled host (host_cpp/: C++ RayTracingManager / RayTracedMesh / ... + .unity loader) == host.py, byte for byte,
+    on scenes written as Unity YAML (spheres + triangle meshes with rotated, non-uniformly scaled transforms)."""
+    from rtx_amd import unity_scene
+    from rtx_amd.host_cpp_binding import CppScene
+    for name, mgr in (("mesh", rtx.scenes.mesh_test_scene(80, 45)), ("spheres", rtx.scenes.config1(64, 64))):
+        path = str(tmp_path / f"{name}.unity")
+        unity_scene.save_unity_scene(mgr, path)
+        cpp = CppScene(path, mgr.width, mgr.height)
+        got = cpp.build_buffers()
+        want = unity_scene.load_unity_scene(path, mgr.width, mgr.height).build_buffers()
+        direct = mgr.build_buffers()
+        for g, w, d, what in zip(got, want, direct, ("params", "spheres", "triangles", "meshinfo")):
+            assert g.tobytes() == w.tobytes(), f"{name}: C++ {what} differ from the Python loader's"
+            assert g.tobytes() == d.tobytes(), f"{name}: C++ {what} differ from the in-memory manager's"
+        assert cpp.counts["serialisedTriangles"] == len(got[2])
+        cpp.close()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Assets/Scenes"), reason="reference scenes only exist in the authoring container")
+def test_cpp_host_loads_the_reference_scenes_unchanged():
+    """All six Assets/Scenes/*.unity through the C++ loader: totals equal the ones the reference serialised
+    (RayTracingManager.cs:156-157) and the buffers equal the Python loader's byte for byte."""
+    import glob
+    import rtx_pkg
+    rtx = rtx_pkg.load()
+    from rtx_amd import unity_scene
+    from rtx_amd.host_cpp_binding import CppScene
+    scenes = sorted(glob.glob("/root/reference/Assets/Scenes/*.unity"))
+    assert len(scenes) == 6
+    for p in scenes:
+        cpp = CppScene(p, 320, 180)
+        got = cpp.build_buffers()
+        assert cpp.counts["chunks"] == cpp.counts["serialisedChunks"] and cpp.counts["triangles"] == cpp.counts["serialisedTriangles"], p
+        want = unity_scene.load_unity_scene(p, 320, 180).build_buffers()
+        for g, w in zip(got, want):
+            assert g.tobytes() == w.tobytes(), p
+        cpp.close()
