@@ -87,3 +87,35 @@ def test_cpp_manager_renders_the_same_image(rtx, tracer, tmp_path):
     got = cpp.render(2)
     cpp.close()
     assert_bitwise(got, want, "C++ host")
+
+
+def test_config5_million_triangles_crop_vs_oracle(rtx, oracle, tracer):
+    """configs[4]: 1,004,364 triangles, depth of field on — a 24x6 window of the 320x180 image against the oracle's flat
+    loop over all 74k chunks (the deep BVH must return the reference's closest hit)."""
+    m = rtx.scenes.config5(320, 180)
+    m.numRaysPerPixel, m.maxBounceCount = 2, 3
+    b = m.build_buffers()
+    assert len(b[2]) == 1004364
+    _, last = run_gpu(tracer, b, 0, 1)
+    rect = (148, 60, 172, 66)
+    want, cnt = oracle.render_frame(*b, 0, rect)
+    assert cnt["boxTests"] > 1e7 and cnt["triTests"] > 1e4
+    assert_bitwise(last[rect[1]:rect[3], rect[0]:rect[2]], want, "config5 crop")
+    st = tracer.stats()
+    assert st["numTriangles"] == 1004364 and st["numBvhNodes"] > 100000
+
+
+def test_4k_bands_of_one_rank_match_the_full_frame(rtx, tracer):
+    """configs[3] geometry at 3840x2160: the bands of rank 5 of 8 equal the same rows of the undivided frame."""
+    m = rtx.scenes.config4()
+    m.numRaysPerPixel, m.maxBounceCount = 1, 12
+    b = m.build_buffers()
+    full, _ = run_gpu(tracer, b, 0, 1)
+    rows = rtx.distributed.band_rows(2160, 8, 5)
+    tracer.set_bands(5, 8)
+    tracer.reset_accum()
+    tracer.render(0, 1)
+    got = tracer.read_accum()
+    tracer.set_rows(0, 2160)
+    assert got.shape[0] == len(rows) == 272
+    assert_bitwise(got, full[rows], "4K bands of rank 5/8")
