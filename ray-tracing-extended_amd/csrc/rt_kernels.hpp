@@ -216,6 +216,11 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
         const v3 inv = slab.inv;                                        // RayBoundingBox :179
         int sp = 0;
         uint32_t cur = 0;                                               // root
+        // The top of the stack lives in a register: a pop hands it out at once and refills it from LDS, so the LDS read's
+        // latency falls before the *next* pop instead of in front of the next node's address.
+        uint32_t top = kNone;
+#define RT_PUSH(X) { if (top != kNone) stk.push(sp, top); top = (X); }
+#define RT_POP()   { cur = top; top = (sp > 0) ? stk.pop(sp) : kNone; }
         while (cur != kNone) {
             // ---- descend internal nodes until this lane holds a leaf (or ran dry)
             while ((int)cur >= 0) {
@@ -225,12 +230,11 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                 uint32_t c0, c1, c2, c3;
                 node_step(S.nodes, cur, slab, best.t, full_sort, t0, t1, t2, t3, c0, c1, c2, c3);
                 const float INF = __builtin_inff();
-                if (t3 < INF) stk.push(sp, c3);
-                if (t2 < INF) stk.push(sp, c2);
-                if (t1 < INF) stk.push(sp, c1);
+                if (t3 < INF) RT_PUSH(c3)
+                if (t2 < INF) RT_PUSH(c2)
+                if (t1 < INF) RT_PUSH(c1)
                 if (t0 < INF) cur = c0;
-                else if (sp > 0) cur = stk.pop(sp);
-                else cur = kNone;
+                else RT_POP()
             }
             // ---- leaf
             if (cur != kNone) {
@@ -261,10 +265,11 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                         if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                     }
                 }
-                if (sp > 0) cur = stk.pop(sp);
-                else cur = kNone;
+                RT_POP()
             }
         }
+#undef RT_PUSH
+#undef RT_POP
     }
     if (COUNT && best.id != kNone) cnt.hits++;
     return best;

@@ -1,0 +1,142 @@
+"""Edge cases the reference's semantics define: empty and ragged inputs, zero bounces, special material
+flags, axis-aligned rays (exact zero direction components -> infinite reciprocals), degenerate primitives, depth of field.
+Every case: GPU (all three kernels where cheap) == oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bitwise, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def check(rtx, oracle, tracer, mgr, frames=2, first=0, kernels=(0, 1, 2), what=""):
+    b = mgr.build_buffers()
+    want, want_last, _ = oracle.render(*b, first, frames)
+    for k in kernels:
+        acc, last = run_gpu(tracer, b, first, frames, kernel=k)
+        assert_bitwise(last, want_last, f"{what} kernel {k} last frame")
+        assert_bitwise(acc, want, f"{what} kernel {k} accum")
+    return want
+
+
+def test_empty_scene_is_pure_environment(rtx, oracle, tracer):
+    m = rtx.scenes.config1(48, 32)
+    m.spheres = []
+    img = check(rtx, oracle, tracer, m, what="empty scene")
+    assert img[..., :3].max() > 0
+
+
+def test_environment_disabled_and_nothing_to_hit_is_black(rtx, oracle, tracer):
+    m = rtx.scenes.config1(32, 24)
+    m.spheres = []
+    m.environmentSettings.enabled = False
+    img = check(rtx, oracle, tracer, m, what="black")
+    assert np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
+
+
+def test_zero_bounces_one_ray(rtx, oracle, tracer):
+    """maxBounceCount = 0: the loop bound is inclusive (RayTracing.shader:305), one cast per path."""
+    m = rtx.scenes.mesh_test_scene(64, 40)
+    m.maxBounceCount, m.numRaysPerPixel = 0, 1
+    check(rtx, oracle, tracer, m, what="B=0")
+
+
+def test_many_bounces_specular_hall_of_mirrors(rtx, oracle, tracer):
+    m = rtx.scenes.config2(96, 54)
+    m.maxBounceCount, m.numRaysPerPixel = 30, 3
+    check(rtx, oracle, tracer, m, frames=1, what="B=30")
+
+
+def test_ragged_chunks_zero_triangle_chunk_and_unreferenced_triangles(rtx, oracle, tracer):
+    """A chunk with numTriangles = 0 and triangles no chunk refers to (the shader can never reach them)."""
+    m = rtx.scenes.mesh_test_scene(64, 40)
+    params, spheres, tris, infos = m.build_buffers()
+    infos = infos.copy()
+    empty = infos[:1].copy()
+    empty["numTriangles"] = 0
+    infos = np.concatenate([infos[:3], empty, infos[3:]])
+    infos["numTriangles"][5] -= 3                      # the last 3 triangles of that chunk become unreachable
+    b = (params, spheres, tris, infos)
+    want, want_last, _ = oracle.render(*b, 0, 1)
+    for k in (0, 1, 2):
+        acc, last = run_gpu(tracer, b, 0, 1, kernel=k)
+        assert_bitwise(last, want_last, f"ragged chunks kernel {k}")
+
+
+def test_axis_aligned_rays_zero_direction_components(rtx, oracle, tracer):
+    """Identity camera, odd resolution, no jitter: the centre column / row have dir.x == 0 / dir.y == 0 exactly, so
+    1/dir is infinite and the slab tests see inf and NaN (RayBoundingBox :179-186)."""
+    h = rtx.host
+    m = rtx.scenes.mesh_test_scene(33, 21)
+    m.camera = h.Camera(h.Transform(position=(0.0, 1.0, -6.0)), fieldOfView=40.0, aspect=33 / 21)
+    m.divergeStrength = m.defocusStrength = 0.0
+    m.numRaysPerPixel, m.maxBounceCount = 2, 3
+    b = m.build_buffers()
+    assert float(b[0]["camLocalToWorld"][1]) == 0.0
+    for mode in (0, 1):
+        mm = m
+        mm.intersectMode = mode
+        check(rtx, oracle, tracer, mm, frames=1, what=f"axis-aligned mode {mode}")
+
+
+def test_depth_of_field_and_invisible_light(rtx, oracle, tracer):
+    """Chess.unity settings (defocus 180, diverge 1, focus 3.82) on the reference scene: exercises the defocus jitter
+    (frag :377-378) and the InvisibleLightSource flag at bounce 0 (Trace :318-322)."""
+    import os
+    from rtx_amd import unity_scene
+    m = unity_scene.load_scene_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "Chess.npz"), 80, 45)
+    m.numRaysPerPixel, m.maxBounceCount = 2, 3
+    assert m.defocusStrength == 180 and any(mesh.materials[0].flag == 2 for mesh in m.meshes)
+    check(rtx, oracle, tracer, m, frames=1, kernels=(0, 1), what="DOF + invisible light")
+
+
+def test_degenerate_primitives(rtx, oracle, tracer):
+    """Zero-radius sphere, zero-area triangle, sliver below the absolute determinant threshold 1e-6 (RayTriangle :169)."""
+    h = rtx.host
+    m = rtx.scenes.mesh_test_scene(48, 32)
+    m.spheres.append(h.RayTracedSphere(h.Transform(position=(0, 1, -2), lossyScale=(0, 0, 0)), h.RayTracingMaterial()))
+    tri = np.zeros(3, rtx.TRIANGLE)
+    tri["posA"], tri["posB"], tri["posC"] = [(0, 1, -3)] * 3, [(0, 1, -3), (1, 1, -3), (1e-4, 1, -3)], [(0, 1, -3), (2, 1, -3), (0, 1 + 1e-4, -3)]
+    tri["normalA"] = tri["normalB"] = tri["normalC"] = (0, 0, -1)
+    m.meshes.append(h.RayTracedMesh(h.Transform(), [h.RayTracingMaterial()], rtx.scenes.chunked(tri)))
+    check(rtx, oracle, tracer, m, frames=1, what="degenerate")
+
+
+def test_one_pixel_and_thin_images(rtx, oracle, tracer):
+    for w, hgt in ((1, 1), (7, 1), (1, 9), (65, 3)):
+        m = rtx.scenes.config1(w, hgt)
+        check(rtx, oracle, tracer, m, frames=1, what=f"{w}x{hgt}")
+
+
+def test_zero_sized_target_is_legal(rtx, tracer):
+    params, spheres, tris, infos = rtx.scenes.config1(16, 8).build_buffers()
+    params = params.copy()
+    params["height"] = 0
+    acc, last = run_gpu(tracer, (params, spheres, tris, infos), 0, 1)
+    assert acc.shape == (0, 16, 4)
+
+
+def test_error_codes_not_exceptions_across_the_abi(rtx, tracer):
+    """Bad input comes back as a status code + message (the reference's only error is the 1500-triangle exception)."""
+    params, spheres, tris, infos = rtx.scenes.mesh_test_scene(16, 16).build_buffers()
+    bad = infos.copy()
+    bad["firstTriangleIndex"][-1] = len(tris)           # range beyond the triangle buffer
+    tracer.set_rows(0, 16)
+    tracer.set_params(params)
+    tracer.upload(spheres=spheres, triangles=tris, meshinfo=bad)
+    with pytest.raises(rtx.RtError, match="beyond"):
+        tracer.render(0, 1)
+    overlap = infos.copy()
+    overlap["firstTriangleIndex"][1] = overlap["firstTriangleIndex"][0]
+    tracer.upload(meshinfo=overlap)
+    with pytest.raises(rtx.RtError, match="referenced by chunks"):
+        tracer.render(0, 1)
+    with pytest.raises(rtx.RtError, match="unknown option"):
+        tracer.set_option("no_such_option", 1)
+    p = params.copy()
+    p["rngMode"] = 7
+    with pytest.raises(rtx.RtError, match="rngMode"):
+        tracer.set_params(p)
+    tracer.upload(meshinfo=infos)                       # leave the shared context usable
+    tracer.set_params(params)
+    tracer.render(0, 1)
