@@ -86,6 +86,7 @@ struct rt_ctx {
     int opt_tile_sync = 1;
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 1;
+    int opt_tile_w_log2 = 3;        // k_trace: tile width 2^n (n = 3: 8x8 tiles)
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
@@ -374,7 +375,13 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     rtk::FrameArgs F{};
     F.p = c->params;
     F.row0 = c->target_row0; F.nrows = c->target_rows; F.row_stride = c->target_row_stride;
+    F.tile_w_log2 = 3;
     F.tiles_x = (c->target_w + 7) / 8; F.tiles_y = (c->target_rows + 7) / 8;
+    if (c->opt_kernel == 0 && c->opt_tile_w_log2 != 3) {        // k_trace only: other tile shapes (same 64 pixels per wave)
+        F.tile_w_log2 = c->opt_tile_w_log2;
+        const int tw = 1 << F.tile_w_log2, th = 64 >> F.tile_w_log2;
+        F.tiles_x = (c->target_w + tw - 1) / tw; F.tiles_y = (c->target_rows + th - 1) / th;
+    }
     const bool stream = c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
     const bool pooled = c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
@@ -652,6 +659,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }
     else if (!std::strcmp(name, "max_leaf")) { if (value < 1 || value > rtbvh::kMaxLeaf) return fail(c, -2, "max_leaf must be in [1,4]"); if (value != c->opt_max_leaf) c->scene_dirty = true; c->opt_max_leaf = value; }
+    else if (!std::strcmp(name, "tile_w_log2")) { if (value < 0 || value > 6) return fail(c, -2, "tile_w_log2 must be in [0,6]"); c->opt_tile_w_log2 = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }

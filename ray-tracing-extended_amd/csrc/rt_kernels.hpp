@@ -44,6 +44,7 @@ struct FrameArgs {
     int row0, nrows;            // rows rendered by this launch: local row ly -> global row row0 + (ly/8)*row_stride + ly%8
     int row_stride;             // 8: one contiguous strip; 8*N: every N-th 8-row band (interleaved decomposition)
     int tiles_x, tiles_y;
+    int tile_w_log2;            // k_trace: a wave's tile is 2^tile_w_log2 pixels wide and 64 >> tile_w_log2 rows tall (3: 8x8)
     int stack_cap;              // LDS stack entries per lane
     int full_sort;              // 1: sort all four children of a node by distance, 0: nearest first only
     uint32_t* gstack;           // overflow of the traversal stack beyond stack_cap ([entry][lane of the launch]); may be null
@@ -478,9 +479,10 @@ __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, 
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= (unsigned)ntiles) break;
         const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-        const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+        const int tw = F.tile_w_log2, th = 6 - tw;
+        const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
-            const int y = F.row0 + ty * F.row_stride + (lane >> 3);
+            const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
             v3 c = render_pixel<COUNT, FLAT>(S, F.p, F.full_sort != 0, F.frame, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[pi] = make_float4(c.x, c.y, c.z, 1.0f);                        // frag :388
