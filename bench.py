@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--decomposition", choices=["bands", "strips"], default="bands",
                     help="N>1: interleaved 8-row bands (balanced, default) or N contiguous strips")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--rng", choices=["pcg", "philox"], default="pcg", help="pcg = the reference's stream (parity mode, headline); philox = counter-based mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
     return ap.parse_args()
@@ -117,6 +118,10 @@ def main():
     mgr = build_workload(rtx, args)
     buffers = mgr.build_buffers()
     params, spheres, tris, infos = buffers
+    if args.rng == "philox":
+        params = params.copy()
+        params["rngMode"] = 1
+        buffers = (params, spheres, tris, infos)
     W, H = int(params["width"]), int(params["height"])
     banded = world > 1 and args.decomposition == "bands"
     if banded:      # 8-row bands dealt round-robin: sky rows and object rows spread evenly over the ranks
@@ -225,7 +230,7 @@ def main():
         "ms_per_step": round(wall / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{names[args.config]}, {W}x{H}, {int(params['numRaysPerPixel'])} rays/pixel/frame "
-                               f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, PCG, FLAT_CHUNKS semantics",
+                               f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, {args.rng.upper()}, FLAT_CHUNKS semantics",
                    "decomposition": (f"{world} ranks, " + ("interleaved 8-row bands" if banded else "contiguous row strips")
                                      + " + one RCCL gather") if world > 1 else "single GPU",
                    "rays_per_frame": int(total_rays / max(args.steps, 1)),

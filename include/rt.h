@@ -81,7 +81,11 @@ typedef struct rt_local_chunk {         /* 80 B: one MeshChunk of RayTracedMesh.
  * (RayTracingManager.cs:113-123,131-132) plus the three Unity built-ins the shader reads
  * (_ScreenParams.xy, _WorldSpaceCameraPos, _WorldSpaceLightPos0: RayTracing.shader:359,378,247).     */
 
-enum { RT_RNG_PCG = 0 };                /* RayTracing.shader:193-204 (the only parity mode)            */
+enum {
+    RT_RNG_PCG = 0,                     /* RayTracing.shader:193-204 — the reference's stream, the parity mode            */
+    RT_RNG_PHILOX = 1                   /* counter-based Philox4x32-10, key (pixelIndex, Frame), draw i = word i&3 of
+                                           block i>>2; NOT the reference's stream (different noise, same estimator)     */
+};
 enum {
     RT_INTERSECT_FLAT_CHUNKS = 0,       /* literal reference result: a triangle counts only if its chunk's
                                            RayBoundingBox test passes (RayTracing.shader:276-294)          */

@@ -193,16 +193,45 @@ float orc_random_value(uint32_t* state)
 {
     return (float)orc_next_random(state) * 2.3283064365386963e-10f;           /* r / 2^32 (shader :203) */
 }
+/* Counter-based alternative (rngMode = RT_RNG_PHILOX; not a reference mode — the north-star's perf mode): Philox4x32-10
+ * (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11).  Draw number i of a pixel in a frame, in the order
+ * the shader draws, is word i&3 of philox(counter = (i>>2, 0, 0, 0), key = (pixelIndex, Frame)). */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct { int mode; uint32_t state, key[2], cache[4]; } orng;     /* state: PCG state, or the Philox draw counter */
+
+static float rnd(orng* g)
+{
+    if (g->mode == RT_RNG_PCG) return orc_random_value(&g->state);
+    if ((g->state & 3u) == 0u) {
+        uint32_t ctr[4] = { g->state >> 2, 0u, 0u, 0u };
+        orc_philox4x32_10(ctr, g->key, g->cache);
+    }
+    uint32_t r = g->cache[g->state & 3u];
+    g->state++;
+    return (float)r * 2.3283064365386963e-10f;
+}
+
 /* RayTracing.shader:207-213 */
-static float random_normal(uint32_t* state)
+static float random_normal(orng* state)
 {
     const float TWO_PI = 2.0f * 3.1415926f;
-    float theta = TWO_PI * orc_random_value(state);
-    float rho = sqrtf(-2.0f * om_log(orc_random_value(state)));
+    float theta = TWO_PI * rnd(state);
+    float rho = sqrtf(-2.0f * om_log(rnd(state)));
     return rho * om_cos(theta);
 }
 /* RayTracing.shader:216-223 */
-static v3 random_direction(uint32_t* state)
+static v3 random_direction(orng* state)
 {
     float x = random_normal(state);
     float y = random_normal(state);
@@ -210,12 +239,12 @@ static v3 random_direction(uint32_t* state)
     return v_normalize(V(x, y, z));
 }
 /* RayTracing.shader:225-230 with PI = 3.1415 (:35) */
-static void random_point_in_circle(uint32_t* state, float* px, float* py)
+static void random_point_in_circle(orng* state, float* px, float* py)
 {
     const float PI = 3.1415f;
-    float angle = orc_random_value(state) * 2.0f * PI;
+    float angle = rnd(state) * 2.0f * PI;
     float cx = om_cos(angle), cy = om_sin(angle);
-    float s = sqrtf(orc_random_value(state));
+    float s = sqrtf(rnd(state));
     *px = cx * s;
     *py = cy * s;
 }
@@ -346,7 +375,7 @@ static v3 environment_light(const rt_params* p, v3 d)
 static inline float mod2(float x) { return x - 2.0f * floorf(x / 2.0f); }
 
 /* Trace :300-352 */
-static v3 trace(const scene_t* sc, v3 o, v3 d, uint32_t* rng, orc_counts* cnt)
+static v3 trace(const scene_t* sc, v3 o, v3 d, orng* rng, orc_counts* cnt)
 {
     const rt_params* p = sc->p;
     v3 incomingLight = V(0, 0, 0);
@@ -364,7 +393,7 @@ static v3 trace(const scene_t* sc, v3 o, v3 d, uint32_t* rng, orc_counts* cnt)
                 o = v_add(h.hitPoint, v_scale(d, 0.001f));
                 continue;
             }
-            int isSpecular = m->specularProbability >= orc_random_value(rng);  /* :325 */
+            int isSpecular = m->specularProbability >= rnd(rng);  /* :325 */
             float specF = isSpecular ? 1.0f : 0.0f;
             o = h.hitPoint;                                                    /* :327 */
             v3 diffuseDir = v_normalize(v_add(h.normal, random_direction(rng)));
@@ -376,7 +405,7 @@ static v3 trace(const scene_t* sc, v3 o, v3 d, uint32_t* rng, orc_counts* cnt)
             rayColour = v_mul(rayColour, v_lerp(colour, v_load(m->specularColour), specF));
 
             float pr = om_max(rayColour.x, om_max(rayColour.y, rayColour.z));  /* :338-342 */
-            if (orc_random_value(rng) >= pr) break;
+            if (rnd(rng) >= pr) break;
             float inv = 1.0f / pr;
             rayColour = v_scale(rayColour, inv);
         } else {
@@ -396,7 +425,10 @@ static void frag(const scene_t* sc, int x, int y, int frame, float* out, orc_cou
     float Wf = (float)W, Hf = (float)H;
     float uvx = ((float)x + 0.5f) / Wf, uvy = ((float)y + 0.5f) / Hf;
     uint32_t pixelIndex = (uint32_t)y * W + (uint32_t)x;
-    uint32_t rng = pixelIndex + (uint32_t)frame * 719393u;
+    orng rng;
+    rng.mode = p->rngMode;
+    rng.state = (p->rngMode == RT_RNG_PCG) ? pixelIndex + (uint32_t)frame * 719393u : 0u;      /* :362 */
+    rng.key[0] = pixelIndex; rng.key[1] = (uint32_t)frame;
 
     float lx = (uvx - 0.5f) * p->viewParams[0];
     float ly = (uvy - 0.5f) * p->viewParams[1];

@@ -382,11 +382,13 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         const int tw = 1 << F.tile_w_log2, th = 64 >> F.tile_w_log2;
         F.tiles_x = (c->target_w + tw - 1) / tw; F.tiles_y = (c->target_rows + th - 1) / th;
     }
-    const bool stream = c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
-    const bool pooled = c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
+    const bool philox = c->params.rngMode == RT_RNG_PHILOX;         // served by k_trace's Philox instantiation only
+    if (philox && var == Variant::Flat) return fail(c, -2, "the flat validation kernel implements the PCG stream only");
+    const bool stream = !philox && c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
+    const bool pooled = !philox && c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // k_stream's branch-free push writes up to 3 slots past the top
-    const bool tile_kernel = !stream && !pooled && var != Variant::Flat;
+    const bool tile_kernel = !stream && !pooled && var != Variant::Flat;   // k_trace, PCG or Philox
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     F.full_sort = c->opt_full_sort;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
@@ -400,6 +402,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
                    : pooled ? (var == Variant::Fast ? (const void*)rtk::k_pool<false> : (const void*)rtk::k_pool<true>)
                    : stream ? (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>)
+                   : philox ? (var == Variant::Fast ? (const void*)rtk::k_trace<false, false, true> : (const void*)rtk::k_trace<true, false, true>)
                             : (var == Variant::Fast ? (const void*)rtk::k_trace<false, false> : (const void*)rtk::k_trace<true, false>);
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
@@ -441,6 +444,9 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         } else if (stream) {
             if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
             else                      hipLaunchKernelGGL((rtk::k_stream<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+        } else if (philox) {
+            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_trace<false, false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
+            else                      hipLaunchKernelGGL((rtk::k_trace<true, false, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
         } else {
             if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_trace<false, false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
             else                      hipLaunchKernelGGL((rtk::k_trace<true, false>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
@@ -562,7 +568,7 @@ int rt_set_params(rt_ctx* c, const rt_params* p)
     if (!p) return fail(c, -2, "null params");
     if (p->width < 0 || p->height < 0 || (int64_t)p->width * p->height > (int64_t)1 << 31) return fail(c, -2, "bad target size %dx%d", p->width, p->height);
     if (p->numRaysPerPixel < 0) return fail(c, -2, "numRaysPerPixel < 0");
-    if (p->rngMode != RT_RNG_PCG) return fail(c, -2, "unknown rngMode %d", p->rngMode);
+    if (p->rngMode != RT_RNG_PCG && p->rngMode != RT_RNG_PHILOX) return fail(c, -2, "unknown rngMode %d", p->rngMode);
     if (p->intersectMode != RT_INTERSECT_FLAT_CHUNKS && p->intersectMode != RT_INTERSECT_BRUTE) return fail(c, -2, "unknown intersectMode %d", p->intersectMode);
     c->params = *p; c->have_params = true;
     return 0;

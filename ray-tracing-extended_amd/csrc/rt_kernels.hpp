@@ -16,6 +16,7 @@
 //     traversal stack lives in LDS (stack[entry][lane], one bank per lane, conflict-free);
 //   * accumulate (Accumulate.shader:43-54) is fused into the epilogue: 16 B read + 2 x 16 B write per pixel.
 #pragma once
+#include <type_traits>
 #include "rt_math.hpp"
 #include "bvh.hpp"
 #include "../../include/rt.h"
@@ -332,7 +333,8 @@ __device__ __forceinline__ float mod2(float x) { return x - 2.0f * __builtin_flo
 struct Camera { v3 focusPoint, right, up, pos; float W; };
 
 // frag :377-382 — one camera ray (4 RNG draws)
-__device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, uint32_t& rng, v3& o, v3& d)
+template <class R>
+__device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, R& rng, v3& o, v3& d)
 {
     float jx, jy;
     rtm::random_point_in_circle(rng, jx, jy);
@@ -345,7 +347,7 @@ __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, 
 }
 
 // One pixel of one frame: frag :356-389 as a flat state machine (see file header).
-template <bool COUNT, bool FLAT>
+template <bool COUNT, bool FLAT, bool PHILOX>
 __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, int frame, int x, int y,
                                            const TravStack& stk, Counters& cnt)
 {
@@ -354,7 +356,9 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
     Camera cam;
     cam.W = (float)W;
     const float uvx = ((float)x + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
-    uint32_t rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)frame * 719393u;           // :361-362
+    typename std::conditional<PHILOX, rtm::PhiloxRng, uint32_t>::type rng;
+    if constexpr (PHILOX) rng.init((uint32_t)y * W + (uint32_t)x, (uint32_t)frame);
+    else rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)frame * 719393u;                 // :361-362
     {
         float lx = (uvx - 0.5f) * p.viewParams[0], ly = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * ly) + M[2]  * lz) + M[3]  * 1.0f,
@@ -459,7 +463,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
 constexpr int kBlock = 256;         // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 
-template <bool COUNT, bool FLAT>
+template <bool COUNT, bool FLAT, bool PHILOX = false>
 __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, FrameArgs F)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, 
         const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
-            v3 c = render_pixel<COUNT, FLAT>(S, F.p, F.full_sort != 0, F.frame, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT, PHILOX>(S, F.p, F.full_sort != 0, F.frame, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[pi] = make_float4(c.x, c.y, c.z, 1.0f);                        // frag :388
             float4 prev = F.accum[pi];                                                 // Accumulate.shader:45-50

@@ -163,8 +163,36 @@ __device__ __forceinline__ float random_value(uint32_t& state)
 {
     return (float)next_random(state) * 2.3283064365386963e-10f;   // r / 2^32 (the shader's 4294967295.0 is a float32 literal)
 }
+// ---- counter-based alternative (rt_params.rngMode = RT_RNG_PHILOX): Philox4x32-10, key (pixelIndex, Frame); draw number i
+// of the pixel (in the shader's draw order) is word i&3 of block i>>2.  Four words are kept in registers and shifted out.
+struct PhiloxRng {
+    uint32_t i, k0, k1, v0, v1, v2, v3;
+    __device__ __forceinline__ void init(uint32_t pixelIndex, uint32_t frame) { i = 0; k0 = pixelIndex; k1 = frame; v0 = v1 = v2 = v3 = 0; }
+    __device__ __forceinline__ void block()
+    {
+        uint32_t c0 = i >> 2, c1 = 0, c2 = 0, c3 = 0, a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            c0 = hi1 ^ c1 ^ a; c1 = lo1; c2 = hi0 ^ c3 ^ b; c3 = lo0;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        v0 = c0; v1 = c1; v2 = c2; v3 = c3;
+    }
+};
+__device__ __forceinline__ float random_value(PhiloxRng& g)
+{
+    if ((g.i & 3u) == 0u) g.block();
+    const uint32_t r = g.v0;
+    g.v0 = g.v1; g.v1 = g.v2; g.v2 = g.v3;
+    g.i++;
+    return (float)r * 2.3283064365386963e-10f;
+}
+
 // RayTracing.shader:207-213
-__device__ __forceinline__ float random_normal(uint32_t& state)
+template <class R>
+__device__ __forceinline__ float random_normal(R& state)
 {
     const float TWO_PI = 2.0f * 3.1415926f;
     float theta = TWO_PI * random_value(state);
@@ -172,7 +200,8 @@ __device__ __forceinline__ float random_normal(uint32_t& state)
     return rho * cos_(theta);
 }
 // RayTracing.shader:216-223
-__device__ __forceinline__ v3 random_direction(uint32_t& state)
+template <class R>
+__device__ __forceinline__ v3 random_direction(R& state)
 {
     float x = random_normal(state);
     float y = random_normal(state);
@@ -180,7 +209,8 @@ __device__ __forceinline__ v3 random_direction(uint32_t& state)
     return normalize(mk(x, y, z));
 }
 // RayTracing.shader:225-230, PI = 3.1415 (:35)
-__device__ __forceinline__ void random_point_in_circle(uint32_t& state, float& px, float& py)
+template <class R>
+__device__ __forceinline__ void random_point_in_circle(R& state, float& px, float& py)
 {
     const float PI = 3.1415f;
     float angle = random_value(state) * 2.0f * PI;

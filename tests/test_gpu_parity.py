@@ -163,3 +163,20 @@ def test_display_srgb8_matches_oracle(rtx, oracle, tracer, tmp_path):
     rtx.imageio.write_png(str(tmp_path / "c1.png"), got)
     rtx.imageio.write_pfm(str(tmp_path / "c1.pfm"), acc)
     assert (tmp_path / "c1.png").stat().st_size > 1000
+
+
+@pytest.mark.parametrize("scene", ["spheres", "mesh"])
+def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene):
+    """rt_params.rngMode = RT_RNG_PHILOX (counter-based Philox4x32-10, key = (pixelIndex, Frame)): GPU == oracle twin."""
+    m = rtx.scenes.config1(96, 64) if scene == "spheres" else rtx.scenes.mesh_test_scene(96, 64)
+    params, spheres, tris, infos = m.build_buffers()
+    params = params.copy()
+    params["rngMode"] = 1
+    b = (params, spheres, tris, infos)
+    for kernel in (0, 2):                       # kernel option 2 is served by the same Philox instantiation of k_trace
+        acc, last = run_gpu(tracer, b, 3, 2, kernel=kernel)
+        want, want_last, _ = oracle.render(*b, 3, 2)
+        assert_bitwise(last, want_last, f"philox {scene} last frame (kernel option {kernel})")
+        assert_bitwise(acc, want, f"philox {scene} accum (kernel option {kernel})")
+    pcg, _ = run_gpu(tracer, (m.build_buffers()[0], spheres, tris, infos), 3, 2)
+    assert not np.array_equal(pcg, acc)

@@ -138,3 +138,29 @@ def test_display_srgb8_known_values(oracle):
     assert out[0].tolist() == [0, 255, 10, 255]
     assert out[1].tolist() == [188, 128, 255, 128]
     assert out[2].tolist() == [0, 0, 63, 255]
+
+
+def test_philox4x32_10_known_answers(oracle):
+    """Random123 known-answer vectors for philox4x32-10 (Salmon et al., SC'11) — pins the counter-based RNG mode."""
+    from ctypes import c_uint32
+    L = oracle.lib
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c, k, o = (c_uint32 * 4)(*ctr), (c_uint32 * 2)(*key), (c_uint32 * 4)()
+        L.orc_philox4x32_10(c, k, o)
+        assert tuple(o) == want
+
+
+def test_philox_mode_is_a_different_stream_with_the_same_estimator(rtx, oracle):
+    """rngMode = PHILOX: other noise than PCG, same expectation (means over many samples agree)."""
+    m = rtx.scenes.config1(32, 32)
+    m.numRaysPerPixel = 64
+    b = list(m.build_buffers())
+    pcg, _ = oracle.render_frame(*b, 0)
+    p = b[0].copy(); p["rngMode"] = 1; b[0] = p
+    phx, _ = oracle.render_frame(*b, 0)
+    assert not np.array_equal(pcg, phx)
+    lo = np.minimum(pcg[..., :3], 1).mean(), np.minimum(phx[..., :3], 1).mean()
+    assert abs(lo[0] - lo[1]) < 0.05 * lo[0], lo
