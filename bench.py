@@ -191,13 +191,14 @@ def main():
         per_launch = alg / max(args.steps, 1)
         launch_s = kernel_ms_rank0 / 1e3 / max(args.steps, 1)
         ach = per_launch / launch_s / 1e9
-        traffic = None
+        traffic, pmc_extra = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}"
                 traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None   # measured for the N=1 launch
+                pmc_extra = {k: tj.get(key, {}).get(k) for k in ("l2_hit_rate", "valu_active_frac_per_simd", "ta_busy_frac", "valu_lane_utilisation")} if world == 1 else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -211,7 +212,8 @@ def main():
                                                zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseLanes"], sc["phaseExecs"])},
                     "phase_wave_execs_per_ray": {n: round(e * 64 / max(sc["rays"], 1), 2) for n, e in
                                                  zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseExecs"])},
-                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]}}
+                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]},
+                    "limiter": "VALU issue (cache-resident working set): see pmc", "pmc": pmc_extra}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(rtx, buffers)
