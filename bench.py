@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--rays", type=int, default=0, help="override rays per pixel per frame (default 64)")
-    ap.add_argument("--kernel", type=int, default=-1, help="tuning: 0 tile-per-wave megakernel, 1 streaming megakernel (library default)")
+    ap.add_argument("--kernel", type=int, default=-2, help="tuning: -1 automatic (library default), 0 k_trace, 1 k_stream, 2 k_pool")
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option passed to rt_set_option")
@@ -137,7 +137,7 @@ def main():
         tr.set_bands(rank, world)
     else:
         tr.set_rows(row0, nrows)
-    if args.kernel >= 0:
+    if args.kernel >= -1:
         tr.set_option("kernel", args.kernel)
     if args.shade_threshold:
         tr.set_option("shade_threshold", args.shade_threshold)
@@ -153,7 +153,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup (untimed): also builds the BVH and uploads
+    # ---- setup (untimed): upload, BVH build, and the library's three calibration frames (tile costs for its costliest-first
+    # tile order; k_trace vs k_stream timing for its automatic kernel choice) — then the W warmup steps
+    tr.render(0, 3)
+    tr.reset_accum()
     tr.render(0, max(args.warmup, 0))
     gather = rtx.distributed.gather_image_banded if banded else rtx.distributed.gather_image
     if dist is not None:                      # warm the RCCL communicator
@@ -188,22 +191,25 @@ def main():
         px = nrows * W * args.steps
         alg = (sc["nodeVisits"] * NODE_BYTES + sc["triTests"] * TRI_BYTES + sc["sphereTests"] * SPHERE_BYTES
                + sc["hits"] * HIT_BYTES + px * PIXEL_BYTES)
-        per_launch = alg / max(args.steps, 1)
-        launch_s = kernel_ms_rank0 / 1e3 / max(args.steps, 1)
+        fpl = max(1, int(st.get("lastFramesPerLaunch", 1)))           # frames traced per k_trace launch in the timed region
+        launches = (args.steps + fpl - 1) // fpl if args.steps else 1
+        per_launch = alg / max(launches, 1)
+        launch_s = kernel_ms_rank0 / 1e3 / max(launches, 1)
         ach = per_launch / launch_s / 1e9
         traffic, pmc_extra = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}"
+                key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}_x{fpl}"
                 traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None   # measured for the N=1 launch
                 pmc_extra = {k: tj.get(key, {}).get(k) for k in ("l2_hit_rate", "valu_active_frac_per_simd", "ta_busy_frac", "valu_lane_utilisation")} if world == 1 else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBPS, 5), "traffic": traffic,
-                    "kernel": "k_trace<false,false>", "launch_ms": round(launch_s * 1e3, 3),
+                    "kernel": {0: "k_trace<false,false,false>", 1: "k_stream<false>", 2: "k_pool<false>"}.get(
+                        st.get("autoKernel", -1) if args.kernel < 0 else args.kernel, "k_trace<false,false,false>"), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl, "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "per_ray": {"nodes": round(sc["nodeVisits"] / max(sc["rays"], 1), 2),
                                 "tris": round(sc["triTests"] / max(sc["rays"], 1), 2),

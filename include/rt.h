@@ -133,6 +133,8 @@ typedef struct rt_stats {
     double   totalKernelMs;             /* sum over launches since rt_reset_accum                        */
     double   lastGeometryMs;            /* HIP-event time of the last on-device transform + bounds + re-layout + refit */
     double   lastDisplayMs;             /* HIP-event time of the last linear -> sRGB8 display kernel     */
+    int32_t  lastFramesPerLaunch;       /* frames traced per k_trace launch in the last rt_render (1 = frame by frame) */
+    int32_t  autoKernel;                /* kernel picked by the automatic choice (-1 = not decided yet / not automatic) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -172,12 +174,18 @@ int rt_set_mesh_transforms(rt_ctx* ctx, const rt_mesh_transform* transforms, int
 int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_meshinfo* meshinfo_out, int n_chunks);
 
 /* Tuning knobs; the image never depends on them (tested bitwise).
- *   "kernel"          0 = tile-per-wave megakernel k_trace (default), 1 = k_stream (resumable traversal, stragglers
- *                     deferred), 2 = k_pool (pixel slots in LDS, in-wave ballot/prefix-sum compaction)
+ *   "kernel"          -1 = automatic (default): the first frames after a scene / camera change time k_trace and k_stream on
+ *                     ordinary frames of the render and the faster one takes the rest; 0 = tile-per-wave megakernel k_trace,
+ *                     1 = k_stream (resumable traversal, stragglers deferred), 2 = k_pool (pixel slots in LDS, in-wave
+ *                     ballot/prefix-sum compaction)
  *   "max_leaf"        triangles per BVH leaf, 1..4 (default 2)
  *   "full_sort"       1 = sort all four children of a node by entry distance (default), 0 = nearest first only
+ *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order
+ *   "frame_batch"     k_trace: frames traced per launch by rt_render (0 = auto: as many as fit 1 GiB, 1 = one per launch)
  *   "lds_stack"       k_trace: traversal-stack entries kept in LDS, deeper ones spill to global memory (0 = all in LDS)
- *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst
+ *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst (default 48)
+ *   "node_min"        k_stream: inside a burst the node loop goes on while at least this many lanes hold an internal node (or no
+ *                     lane holds a leaf); below it the leaves are served first (default 6; 1 = classic while-while)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
  *   "pool_stack", "trav_min_lanes"   k_pool: LDS stack entries per lane; in-flight lanes below which TRAVERSE is left
  *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */

@@ -5,6 +5,7 @@
 // accumulation target (resultTexture) and the per-frame target (currentFrame).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -74,6 +75,9 @@ struct rt_ctx {
     DevBuf<uint32_t> d_raw_range;
     DevBuf<float4> d_frame, d_accum;
     DevBuf<uint32_t> d_display;
+    DevBuf<float4> d_batch;            // per-frame outputs of a multi-frame launch
+    DevBuf<uint32_t> d_tile_order, d_tile_cost;
+    bool tile_order_valid = false; int tile_order_n = 0;
     size_t target_pixels = 0;
     int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0, target_row_stride = 8;
     unsigned int* d_tile_counter = nullptr;
@@ -81,11 +85,15 @@ struct rt_ctx {
 
     rtbvh::Bvh bvh;
     int n_cu = 0;
-    int opt_kernel = 0;             // 0: k_trace (tile per wave), 1: k_stream (resumable traversal), 2: k_pool (in-wave compaction)
-    int opt_shade_threshold = 56;
+    int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream, 2: k_pool
+    int auto_choice = -1; double auto_ms[2] = { -1.0, -1.0 };
+    int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
+    int opt_node_min = 6;           // k_stream: measured best 4..8 on the 100k-triangle workload (+7 % over 1)
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 1;
+    int opt_tile_lpt = 1;           // k_trace: dispatch the costliest tiles first, using the costs measured by the previous launch
+    int opt_frame_batch = 0;        // k_trace: frames per launch in rt_render (0 = auto, 1 = one launch per frame)
     int opt_tile_w_log2 = 3;        // k_trace: tile width 2^n (n = 3: 8x8 tiles)
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
@@ -202,7 +210,7 @@ int build_scene(rt_ctx* c)
 
     c->stats.numSpheres = (int)ns; c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->bvh.nodes.size(); c->stats.bvhMaxStack = c->bvh.maxStack;
-    c->scene_dirty = false;
+    c->scene_dirty = false; c->tile_order_valid = false;
     return 0;
 }
 
@@ -318,7 +326,7 @@ int build_scene_local(rt_ctx* c)
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->bvh.nodes.size(); c->stats.bvhMaxStack = c->bvh.maxStack;
-    c->scene_dirty = false; c->xf_dirty = false;
+    c->scene_dirty = false; c->xf_dirty = false; c->tile_order_valid = false;
     return 0;
 }
 
@@ -341,14 +349,15 @@ int ensure_targets(rt_ctx* c)
         RT_HIP(c, hipMemsetAsync(c->d_frame.p, 0, px * sizeof(float4), c->stream));
         RT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, px * sizeof(float4), c->stream));
     }
-    c->target_pixels = px; c->target_w = W; c->target_h = H; c->target_row0 = r0; c->target_rows = nr; c->target_row_stride = rstride;
+    c->target_pixels = px; c->target_w = W; c->target_h = H; c->target_row0 = r0; c->target_rows = nr; c->target_row_stride = rstride; c->tile_order_valid = false;
     c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0;
     return 0;
 }
 
 enum class Variant { Fast, Counting, Flat };
 
-int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
+// One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream, 2 k_pool).
+int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int kernel)
 {
     if (!c) return -1;
     if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
@@ -377,15 +386,15 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     F.row0 = c->target_row0; F.nrows = c->target_rows; F.row_stride = c->target_row_stride;
     F.tile_w_log2 = 3;
     F.tiles_x = (c->target_w + 7) / 8; F.tiles_y = (c->target_rows + 7) / 8;
-    if (c->opt_kernel == 0 && c->opt_tile_w_log2 != 3) {        // k_trace only: other tile shapes (same 64 pixels per wave)
+    if (kernel == 0 && c->opt_tile_w_log2 != 3) {        // k_trace only: other tile shapes (same 64 pixels per wave)
         F.tile_w_log2 = c->opt_tile_w_log2;
         const int tw = 1 << F.tile_w_log2, th = 64 >> F.tile_w_log2;
         F.tiles_x = (c->target_w + tw - 1) / tw; F.tiles_y = (c->target_rows + th - 1) / th;
     }
     const bool philox = c->params.rngMode == RT_RNG_PHILOX;         // served by k_trace's Philox instantiation only
     if (philox && var == Variant::Flat) return fail(c, -2, "the flat validation kernel implements the PCG stream only");
-    const bool stream = !philox && c->opt_kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
-    const bool pooled = !philox && c->opt_kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
+    const bool stream = !philox && kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
+    const bool pooled = !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // k_stream's branch-free push writes up to 3 slots past the top
     const bool tile_kernel = !stream && !pooled && var != Variant::Flat;   // k_trace, PCG or Philox
@@ -418,6 +427,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
     A.total_pixels = (unsigned int)ntiles * 64u;
     A.tile_sync = c->opt_tile_sync;
+    A.node_min = std::max(1, std::min(64, c->opt_node_min));
     rtk::PoolArgs PA{};
     PA.total_pixels = A.total_pixels;
     PA.trav_min_lanes = std::max(1, std::min(64, c->opt_trav_min_lanes));
@@ -432,10 +442,39 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         PA.gstack = c->d_gstack.p;
     }
 
+    // k_trace can trace several frames per launch (work items = (frame, tile)): the persistent waves then balance over
+    // frames as well — what matters when a rank's strip has about as many tiles as the chip has wave slots.
+    int batch = 1;
+    const bool stream_tiles = stream && c->opt_tile_sync;        // k_stream taking whole tiles: same (frame, tile) items as k_trace
+    if ((tile_kernel || stream_tiles) && n_frames > 1 && c->opt_frame_batch != 1) {
+        const size_t budget = (size_t)1 << 30;                                  // <= 1 GiB of per-frame outputs
+        const size_t per_frame = c->target_pixels * sizeof(float4);
+        batch = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, budget / per_frame));
+        if (c->opt_frame_batch > 1) batch = std::min(batch, c->opt_frame_batch);
+        batch = std::min(batch, 256);
+        if (batch > 1) RT_HIP(c, c->d_batch.ensure((size_t)batch * c->target_pixels));
+    }
+    // LPT scheduling of the persistent waves: a launch records every tile's cost; the next ones hand tiles out costliest
+    // first, so the end of a launch is filled with cheap tiles instead of waiting for a few expensive ones.
+    const bool lpt = (tile_kernel || (stream && c->opt_tile_sync)) && c->opt_tile_lpt && ntiles > 1;
+    bool record_costs = false;
+    if (lpt) {
+        if (c->tile_order_n != ntiles) { c->tile_order_valid = false; c->tile_order_n = ntiles; }
+        RT_HIP(c, c->d_tile_cost.ensure(ntiles)); RT_HIP(c, c->d_tile_order.ensure(ntiles));
+        if (!c->tile_order_valid) {
+            record_costs = true;
+            RT_HIP(c, hipMemsetAsync(c->d_tile_cost.p, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
+        }
+        F.tile_order = c->tile_order_valid ? c->d_tile_order.p : nullptr;
+        F.tile_cost = record_costs ? c->d_tile_cost.p : nullptr;
+    }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < n_frames; ++i) {
+    for (int i = 0; i < n_frames; ) {
+        const int nb = batch > 1 ? std::min(batch, n_frames - i) : 1;
         F.frame = first_frame + i;
+        F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
+        F.out_frame = nb > 1 ? c->d_batch.p : c->d_frame.p;
         RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
         if (var == Variant::Flat) hipLaunchKernelGGL((rtk::k_trace<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
         else if (pooled) {
@@ -452,12 +491,28 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
             else                      hipLaunchKernelGGL((rtk::k_trace<true, false>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
         }
         RT_HIP(c, hipGetLastError());
+        if (nb > 1) {
+            const int ag = (int)std::min<size_t>((c->target_pixels + 255) / 256, (size_t)c->n_cu * 8);
+            hipLaunchKernelGGL(rtk::k_accumulate, dim3(ag), dim3(256), 0, c->stream, c->d_batch.p, c->d_accum.p, c->d_frame.p,
+                               c->target_pixels, F.frame_stride, F.frame, nb);
+            RT_HIP(c, hipGetLastError());
+        }
+        i += nb;
     }
+    c->stats.lastFramesPerLaunch = batch;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.lastKernelMs = ms; c->stats.totalKernelMs += ms;
+    if (record_costs) {
+        std::vector<uint32_t> cost(ntiles), order(ntiles);
+        RT_HIP(c, hipMemcpy(cost.data(), c->d_tile_cost.p, (size_t)ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int t = 0; t < ntiles; ++t) order[t] = (uint32_t)t;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        RT_HIP(c, hipMemcpy(c->d_tile_order.p, order.data(), (size_t)ntiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->tile_order_valid = true;
+    }
     c->stats.numRenderedFrames += n_frames;
     {
         unsigned long long h[rtk::kNumCounters];
@@ -471,6 +526,55 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
             for (int k = 0; k < 5; ++k) c->stats.phaseLanes[k] = c->stats.phaseExecs[k] = 0;
         }
     }
+    return 0;
+}
+
+// Kernel choice "auto" (option kernel = -1, the default): k_trace and k_stream (resumable traversal, stragglers deferred)
+// produce the same bits, and which one is faster depends on the scene (measured: k_stream +8 % on the 100k-triangle
+// workload, -5 % on the 1M-triangle one, -13 % on spheres only).  So the first frames after a scene / camera change are
+// used as the measurement: one frame records the tile costs, one is timed with k_trace, one with k_stream (all three are
+// ordinary frames of the render — nothing is traced twice); the faster kernel takes the rest.
+int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
+{
+    if (!c) return -1;
+    const bool eligible = c->opt_kernel < 0 && var != Variant::Flat && c->have_params && c->params.rngMode == RT_RNG_PCG
+                          && c->params.numRaysPerPixel >= 1;
+    if (!eligible) return launch_frames_k(c, first_frame, n_frames, var, c->opt_kernel < 0 ? 0 : c->opt_kernel);
+    if (c->auto_choice >= 0 && !c->scene_dirty && c->tile_order_valid)
+        return launch_frames_k(c, first_frame, n_frames, var, c->auto_choice);
+
+    rt_stats sum{}; bool any = false;
+    auto add = [&]() {
+        const rt_stats& s = c->stats;
+        sum.rays += s.rays; sum.sphereTests += s.sphereTests; sum.nodeVisits += s.nodeVisits; sum.triTests += s.triTests; sum.hits += s.hits;
+        for (int k = 0; k < 5; ++k) { sum.phaseLanes[k] += s.phaseLanes[k]; sum.phaseExecs[k] += s.phaseExecs[k]; }
+        sum.lastKernelMs += s.lastKernelMs; any = true;
+    };
+    int done = 0;
+    while (done < n_frames) {
+        int kernel, count = 1;
+        if (c->scene_dirty || !c->tile_order_valid) { kernel = 0; c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }   // records the tile costs
+        else if (c->auto_choice >= 0) { kernel = c->auto_choice; count = n_frames - done; }
+        else if (c->auto_ms[0] < 0) kernel = 0;
+        else kernel = 1;
+        const bool probing = c->auto_choice < 0 && !c->scene_dirty && c->tile_order_valid;
+        int r = launch_frames_k(c, first_frame + done, count, var, kernel);
+        if (r) return r;
+        add();
+        if (c->target_pixels == 0) { done += count; continue; }
+        if (probing) {
+            c->auto_ms[kernel] = c->stats.lastKernelMs;
+            if (c->auto_ms[0] >= 0 && c->auto_ms[1] >= 0) c->auto_choice = (c->stats.numBvhNodes > 0 && c->auto_ms[1] < c->auto_ms[0]) ? 1 : 0;
+        }
+        done += count;
+    }
+    if (any) {
+        c->stats.rays = sum.rays; c->stats.sphereTests = sum.sphereTests; c->stats.nodeVisits = sum.nodeVisits;
+        c->stats.triTests = sum.triTests; c->stats.hits = sum.hits;
+        for (int k = 0; k < 5; ++k) { c->stats.phaseLanes[k] = sum.phaseLanes[k]; c->stats.phaseExecs[k] = sum.phaseExecs[k]; }
+        c->stats.lastKernelMs = sum.lastKernelMs;
+    }
+    c->stats.autoKernel = c->auto_choice;
     return 0;
 }
 
@@ -543,7 +647,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_display.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -570,6 +674,7 @@ int rt_set_params(rt_ctx* c, const rt_params* p)
     if (p->numRaysPerPixel < 0) return fail(c, -2, "numRaysPerPixel < 0");
     if (p->rngMode != RT_RNG_PCG && p->rngMode != RT_RNG_PHILOX) return fail(c, -2, "unknown rngMode %d", p->rngMode);
     if (p->intersectMode != RT_INTERSECT_FLAT_CHUNKS && p->intersectMode != RT_INTERSECT_BRUTE) return fail(c, -2, "unknown intersectMode %d", p->intersectMode);
+    if (!c->have_params || std::memcmp(&c->params, p, sizeof *p) != 0) { c->tile_order_valid = false; c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }
     c->params = *p; c->have_params = true;
     return 0;
 }
@@ -659,13 +764,16 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
 {
     if (!c) return -1;
     if (!name) return fail(c, -2, "null option name");
-    if (!std::strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail(c, -2, "kernel must be 0, 1 or 2"); c->opt_kernel = value; }
+    if (!std::strcmp(name, "kernel")) { if (value < -1 || value > 2) return fail(c, -2, "kernel must be -1 (auto), 0, 1 or 2"); c->opt_kernel = value; }
     else if (!std::strcmp(name, "pool_stack")) { if (value < 1 || value > 64) return fail(c, -2, "pool_stack must be in [1,64]"); c->opt_pool_stack = value; }
     else if (!std::strcmp(name, "trav_min_lanes")) { if (value < 1 || value > 64) return fail(c, -2, "trav_min_lanes must be in [1,64]"); c->opt_trav_min_lanes = value; }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }
     else if (!std::strcmp(name, "max_leaf")) { if (value < 1 || value > rtbvh::kMaxLeaf) return fail(c, -2, "max_leaf must be in [1,4]"); if (value != c->opt_max_leaf) c->scene_dirty = true; c->opt_max_leaf = value; }
     else if (!std::strcmp(name, "tile_w_log2")) { if (value < 0 || value > 6) return fail(c, -2, "tile_w_log2 must be in [0,6]"); c->opt_tile_w_log2 = value; }
+    else if (!std::strcmp(name, "tile_lpt")) { c->opt_tile_lpt = value ? 1 : 0; c->tile_order_valid = false; }
+    else if (!std::strcmp(name, "frame_batch")) { if (value < 0 || value > 1024) return fail(c, -2, "frame_batch must be in [0,1024]"); c->opt_frame_batch = value; }
+    else if (!std::strcmp(name, "node_min")) { if (value < 1 || value > 64) return fail(c, -2, "node_min must be in [1,64]"); c->opt_node_min = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }

@@ -45,6 +45,10 @@ struct FrameArgs {
     int row0, nrows;            // rows rendered by this launch: local row ly -> global row row0 + (ly/8)*row_stride + ly%8
     int row_stride;             // 8: one contiguous strip; 8*N: every N-th 8-row band (interleaved decomposition)
     int tiles_x, tiles_y;
+    int frames_in_launch;       // k_trace: > 1 = this launch traces frames frame .. frame+n-1 into out_frame[f * frame_stride + pixel]
+    unsigned int frame_stride;  //          and leaves the (ordered) accumulation to k_accumulate
+    const uint32_t* tile_order; // k_trace: item -> tile permutation (costliest tiles first: LPT scheduling of the persistent waves); may be null
+    uint32_t* tile_cost;        // k_trace: per-tile shader-clock cost of this launch (summed over its frames); may be null
     int tile_w_log2;            // k_trace: a wave's tile is 2^tile_w_log2 pixels wide and 64 >> tile_w_log2 rows tall (3: 8x8)
     int stack_cap;              // LDS stack entries per lane
     int full_sort;              // 1: sort all four children of a node by distance, 0: nearest first only
@@ -474,30 +478,42 @@ __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, 
     stk.glb = F.gstack ? F.gstack + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
     Counters cnt = {};
     const int ntiles = F.tiles_x * F.tiles_y;
+    const bool batched = F.frames_in_launch > 1;
+    const unsigned int nitems = (unsigned)ntiles * (unsigned)(batched ? F.frames_in_launch : 1);
     const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48
     const float omw = 1.0f - weight;
 
     for (;;) {
-        unsigned int tile = 0;
-        if (lane == 0) tile = atomicAdd(F.tile_counter, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= (unsigned)ntiles) break;
+        // work item = (frame, tile), frame-major: with several frames per launch the wave count no longer has to be
+        // matched by the tile count for the persistent waves to balance (frames are independent: frag :362 seeds by Frame)
+        unsigned int item = 0;
+        if (lane == 0) item = atomicAdd(F.tile_counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
+        const unsigned int fi = item / (unsigned)ntiles;
+        unsigned int tile = item - fi * (unsigned)ntiles;
+        if (F.tile_order) tile = F.tile_order[tile];
+        const unsigned long long t_begin = F.tile_cost ? __builtin_readcyclecounter() : 0ull;
         const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
         const int tw = F.tile_w_log2, th = 6 - tw;
         const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
-            v3 c = render_pixel<COUNT, FLAT, PHILOX>(S, F.p, F.full_sort != 0, F.frame, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT, PHILOX>(S, F.p, F.full_sort != 0, F.frame + (int)fi, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
-            F.out_frame[pi] = make_float4(c.x, c.y, c.z, 1.0f);                        // frag :388
-            float4 prev = F.accum[pi];                                                 // Accumulate.shader:45-50
-            float4 acc;
-            acc.x = rtm::saturate(prev.x * omw + c.x * weight);
-            acc.y = rtm::saturate(prev.y * omw + c.y * weight);
-            acc.z = rtm::saturate(prev.z * omw + c.z * weight);
-            acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
-            F.accum[pi] = acc;
+            F.out_frame[(size_t)fi * F.frame_stride + pi] = make_float4(c.x, c.y, c.z, 1.0f);     // frag :388
+            if (!batched) {
+                float4 prev = F.accum[pi];                                             // Accumulate.shader:45-50
+                float4 acc;
+                acc.x = rtm::saturate(prev.x * omw + c.x * weight);
+                acc.y = rtm::saturate(prev.y * omw + c.y * weight);
+                acc.z = rtm::saturate(prev.z * omw + c.z * weight);
+                acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
+                F.accum[pi] = acc;
+            }
         }
+        if (F.tile_cost && lane == 0)
+            atomicAdd(&F.tile_cost[tile], (uint32_t)((__builtin_readcyclecounter() - t_begin) >> 6));
     }
     {
         unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
@@ -507,6 +523,27 @@ __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, 
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0) atomicAdd(&F.counters[k], s);
         }
+    }
+}
+
+// Accumulate.shader:43-54 for a batch of frames traced by one launch: per pixel, frames first .. first+n-1 in order.
+__global__ __launch_bounds__(256) void k_accumulate(const float4* __restrict__ frames, float4* __restrict__ accum,
+                                                    float4* __restrict__ last_frame, size_t pixels, unsigned int frame_stride,
+                                                    int first_frame, int n_frames)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pixels; i += (size_t)gridDim.x * blockDim.x) {
+        float4 acc = accum[i], cur = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int f = 0; f < n_frames; ++f) {
+            cur = frames[(size_t)f * frame_stride + i];
+            const float weight = 1.0f / (float)(first_frame + f + 1);
+            const float omw = 1.0f - weight;
+            acc.x = rtm::saturate(acc.x * omw + cur.x * weight);
+            acc.y = rtm::saturate(acc.y * omw + cur.y * weight);
+            acc.z = rtm::saturate(acc.z * omw + cur.z * weight);
+            acc.w = rtm::saturate(acc.w * omw + cur.w * weight);
+        }
+        accum[i] = acc;
+        last_frame[i] = cur;
     }
 }
 

@@ -23,6 +23,7 @@ namespace rtk {
 struct StreamArgs {
     int shade_threshold;        // lanes waiting for SHADE that trigger it
     unsigned int total_pixels;  // tiles_x * tiles_y * 64 (tile-major enumeration, padded)
+    int node_min;               // the node loop of a burst goes on while at least this many lanes hold an internal node (or no lane holds a leaf)
     int tile_sync;              // 1: a wave takes a whole 8x8 tile at a time (coherent lanes), 0: lanes refill pixel by pixel
 };
 
@@ -60,22 +61,33 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
     uint32_t cur = kNone; int sp = 0;
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
+    unsigned int wave_fi = 0;           // frame (offset) of the tile this wave is working on
+    unsigned int wave_tile = 0xFFFFFFFFu; unsigned long long wave_t0 = 0;
 
     for (;;) {
         const int nTrav = __popcll(__ballot(mode == kModeTrav)), nShade = __popcll(__ballot(mode == kModeShade));
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             // ---- the whole wave is done with its tile: take the next one (tile-major order)
+            if (F.tile_cost && wave_tile != 0xFFFFFFFFu && lane == 0)
+                atomicAdd(&F.tile_cost[wave_tile], (uint32_t)((__builtin_readcyclecounter() - wave_t0) >> 6));
+            wave_tile = 0xFFFFFFFFu;
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(F.tile_counter, 64u);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= A.total_pixels) break;
-            const unsigned int tile = base >> 6;
+            const bool batched = F.frames_in_launch > 1;
+            const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
+            unsigned int item = base >> 6;
+            if (item >= ntiles_ * (unsigned)(batched ? F.frames_in_launch : 1)) break;
+            wave_fi = item / ntiles_;                         // work item = (frame, tile), frame-major (as in k_trace)
+            unsigned int tile = item - wave_fi * ntiles_;
+            if (F.tile_order) tile = F.tile_order[tile];
+            wave_tile = tile; wave_t0 = __builtin_readcyclecounter();
             const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (lane & 7);
             const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
             if (x < p.width && yy < F.nrows) {
                 px = x; ly = yy;
-                rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;   // :361-362
+                rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)(F.frame + (int)wave_fi) * 719393u;   // :361-362
                 total = rtm::mk(0.f, 0.f, 0.f);
                 sample = 0; live = false; fresh = true;
                 mode = kModeShade;
@@ -149,14 +161,16 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                             const float n = (float)p.numRaysPerPixel;
                             const float cx = total.x / n, cy = total.y / n, cz = total.z / n;
                             const size_t pi = (size_t)ly * W + (uint32_t)px;
-                            F.out_frame[pi] = make_float4(cx, cy, cz, 1.0f);
-                            const float4 prev = F.accum[pi];
-                            float4 acc;
-                            acc.x = rtm::saturate(prev.x * omw + cx * weight);
-                            acc.y = rtm::saturate(prev.y * omw + cy * weight);
-                            acc.z = rtm::saturate(prev.z * omw + cz * weight);
-                            acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
-                            F.accum[pi] = acc;
+                            F.out_frame[(size_t)wave_fi * F.frame_stride + pi] = make_float4(cx, cy, cz, 1.0f);
+                            if (F.frames_in_launch <= 1) {
+                                const float4 prev = F.accum[pi];
+                                float4 acc;
+                                acc.x = rtm::saturate(prev.x * omw + cx * weight);
+                                acc.y = rtm::saturate(prev.y * omw + cy * weight);
+                                acc.z = rtm::saturate(prev.z * omw + cz * weight);
+                                acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
+                                F.accum[pi] = acc;
+                            }
                             px = -1;
                             if (A.tile_sync) mode = kModeWait;      // idle until the wave's whole tile is done
                         } else need_ray = true;
@@ -228,7 +242,10 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
             // tests its whole leaf.  The burst ends when all queries are complete, or as soon as `shade_threshold`
             // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
             for (;;) {
-                while (__ballot(mode == kModeTrav && (int)cur >= 0) != 0) {
+                for (;;) {
+                    const int nAtNode = __popcll(__ballot(mode == kModeTrav && (int)cur >= 0));
+                    if (nAtNode == 0) break;
+                    if (nAtNode < A.node_min && __ballot(mode == kModeTrav && (int)cur < 0) != 0) break;   // few descenders: serve the leaves first
                     if (mode == kModeTrav && (int)cur >= 0) {
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
@@ -244,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                         else { cur = kNone; mode = kModeShade; }
                     }
                 }
-                if (mode == kModeTrav) {            // (int)cur < 0: a leaf = kLeafBit | first << 2 | count-1
+                if (mode == kModeTrav && (int)cur < 0) {            // a leaf = kLeafBit | first << 2 | count-1
                     uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
                     const uint32_t last = ti + (cur & 3u);
                     for (; ti <= last; ++ti) {

@@ -18,7 +18,7 @@ def assert_bitwise(got, want, what):
                              f"gpu {got[y, x]} oracle {want[y, x]}")
 
 
-def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=0, shade_threshold=56, tile_sync=1):
+def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=0, shade_threshold=48, tile_sync=1):
     params, spheres, tris, infos = buffers
     p = params.copy()
     if mode is not None:
@@ -102,6 +102,25 @@ def test_counting_build_matches_oracle_ray_count(rtx, oracle, tracer):
     assert st["rays"] == cnt["rays"] and st["hits"] == cnt["hits"] and st["sphereTests"] == cnt["sphereTests"]
 
 
+@pytest.mark.parametrize("node_min", [1, 24, 64])
+def test_node_loop_cap_does_not_change_the_image(rtx, oracle, tracer, node_min):
+    """k_stream's node loop may hand over to the leaves while some lanes still hold internal nodes (option node_min):
+    those lanes must simply wait — image and work counters stay the oracle's."""
+    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
+    tracer.set_option("node_min", node_min)
+    try:
+        got, got_last = run_gpu(tracer, b, 2, 2, kernel=1)
+        tracer.reset_accum()
+        tracer.render_counting(2, 2)
+        st = tracer.stats()
+    finally:
+        tracer.set_option("node_min", 6)
+    want, want_last, cnt = oracle.render(*b, 2, 2)
+    assert_bitwise(got_last, want_last, f"node_min={node_min}: last frame")
+    assert_bitwise(got, want, f"node_min={node_min}: accum")
+    assert st["rays"] == cnt["rays"] and st["hits"] == cnt["hits"]
+
+
 @pytest.mark.parametrize("tile_sync", [0, 1])
 @pytest.mark.parametrize("threshold", [1, 13, 64])
 def test_schedule_knobs_do_not_change_the_image(rtx, tracer, threshold, tile_sync):
@@ -180,3 +199,42 @@ def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene):
         assert_bitwise(acc, want, f"philox {scene} accum (kernel option {kernel})")
     pcg, _ = run_gpu(tracer, (m.build_buffers()[0], spheres, tris, infos), 3, 2)
     assert not np.array_equal(pcg, acc)
+
+
+def test_multi_frame_launch_equals_frame_by_frame(rtx, oracle, tracer):
+    """rt_render(first, n) traces n frames per k_trace launch (work items = (frame, tile)) and accumulates them in order
+    afterwards; the result equals n single-frame launches and the oracle (sun at 200x: the clamped running average is
+    order-sensitive)."""
+    b = rtx.scenes.config1(72, 40).build_buffers()
+    tracer.set_option("frame_batch", 1)
+    try:
+        ref, ref_last = run_gpu(tracer, b, 2, 5)
+        assert tracer.stats()["lastFramesPerLaunch"] == 1
+    finally:
+        tracer.set_option("frame_batch", 0)
+    got, got_last = run_gpu(tracer, b, 2, 5)
+    assert tracer.stats()["lastFramesPerLaunch"] == 5
+    tracer.set_option("frame_batch", 2)                      # 2 + 2 + 1
+    try:
+        got2, got2_last = run_gpu(tracer, b, 2, 5)
+    finally:
+        tracer.set_option("frame_batch", 0)
+    want, want_last, _ = oracle.render(*b, 2, 5)
+    for a, l, what in ((ref, ref_last, "frame by frame"), (got, got_last, "one launch"), (got2, got2_last, "batches of 2")):
+        assert_bitwise(l, want_last, f"{what}: last frame")
+        assert_bitwise(a, want, f"{what}: accum")
+
+
+def test_automatic_kernel_choice_is_transparent(rtx, oracle, tracer):
+    """kernel = -1 (default): frames 0..5 are traced by a mix of k_trace / k_stream launches while the library measures
+    which is faster; the image is the oracle's, and the choice is made after three frames."""
+    b = rtx.scenes.mesh_test_scene(96, 64).build_buffers()
+    acc, last = run_gpu(tracer, b, 0, 6, kernel=-1)
+    st = tracer.stats()
+    assert st["autoKernel"] in (0, 1)
+    want, want_last, cnt = oracle.render(*b, 0, 6)
+    assert_bitwise(last, want_last, "auto kernel: last frame")
+    assert_bitwise(acc, want, "auto kernel: accum")
+    assert st["rays"] == cnt["rays"]
+    tracer.render_frame(6)                     # decided: single frames keep using the chosen kernel
+    assert tracer.stats()["autoKernel"] == st["autoKernel"]
