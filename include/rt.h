@@ -179,7 +179,7 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     1 = k_stream (resumable traversal, stragglers deferred), 2 = k_pool (pixel slots in LDS, in-wave
  *                     ballot/prefix-sum compaction)
  *   "max_leaf"        triangles per BVH leaf, 1..4 (default 2)
- *   "full_sort"       1 = sort all four children of a node by entry distance (default), 0 = nearest first only
+ *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order
  *   "frame_batch"     k_trace: frames traced per launch by rt_render (0 = auto: as many as fit 1 GiB, 1 = one per launch)
  *   "lds_stack"       k_trace: traversal-stack entries kept in LDS, deeper ones spill to global memory (0 = all in LDS)

@@ -9,7 +9,7 @@ import os
 import sys
 
 tag = sys.argv[1]
-kernel_filter = sys.argv[2] if len(sys.argv) > 2 else "k_trace"
+kernel_filter = sys.argv[2] if len(sys.argv) > 2 else "k_stream"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 out = {"tag": tag, "kernel_filter": kernel_filter}
