@@ -64,7 +64,7 @@ struct Builder {
             bn[me].first = first; bn[me].count = count;
             return me;
         }
-        constexpr int NB = 16;
+        constexpr int NB = 32;
         int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
         for (int a = 0; a < 3; ++a) {
             float lo = cb.mn[a], ext = cb.mx[a] - cb.mn[a];
