@@ -77,7 +77,7 @@ struct rt_ctx {
     DevBuf<uint32_t> d_display;
     DevBuf<float4> d_batch;            // per-frame outputs of a multi-frame launch
     DevBuf<uint32_t> d_tile_order, d_tile_cost;
-    bool tile_order_valid = false; int tile_order_n = 0;
+    bool tile_order_valid = false, tile_order_stale = false; int tile_order_n = 0;   // stale: usable, re-measured by the next launch
     size_t target_pixels = 0;
     int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0, target_row_stride = 8;
     unsigned int* d_tile_counter = nullptr;
@@ -461,7 +461,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (lpt) {
         if (c->tile_order_n != ntiles) { c->tile_order_valid = false; c->tile_order_n = ntiles; }
         RT_HIP(c, c->d_tile_cost.ensure(ntiles)); RT_HIP(c, c->d_tile_order.ensure(ntiles));
-        if (!c->tile_order_valid) {
+        if (!c->tile_order_valid || c->tile_order_stale) {
             record_costs = true;
             RT_HIP(c, hipMemsetAsync(c->d_tile_cost.p, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
         }
@@ -511,7 +511,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         for (int t = 0; t < ntiles; ++t) order[t] = (uint32_t)t;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
         RT_HIP(c, hipMemcpy(c->d_tile_order.p, order.data(), (size_t)ntiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->tile_order_valid = true;
+        c->tile_order_valid = true; c->tile_order_stale = false;
     }
     c->stats.numRenderedFrames += n_frames;
     {
@@ -674,7 +674,8 @@ int rt_set_params(rt_ctx* c, const rt_params* p)
     if (p->numRaysPerPixel < 0) return fail(c, -2, "numRaysPerPixel < 0");
     if (p->rngMode != RT_RNG_PCG && p->rngMode != RT_RNG_PHILOX) return fail(c, -2, "unknown rngMode %d", p->rngMode);
     if (p->intersectMode != RT_INTERSECT_FLAT_CHUNKS && p->intersectMode != RT_INTERSECT_BRUTE) return fail(c, -2, "unknown intersectMode %d", p->intersectMode);
-    if (!c->have_params || std::memcmp(&c->params, p, sizeof *p) != 0) { c->tile_order_valid = false; c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }
+    // a moved camera keeps the previous frame's tile order and kernel choice as predictors; the next launch re-measures the costs
+    if (!c->have_params || std::memcmp(&c->params, p, sizeof *p) != 0) c->tile_order_stale = true;
     c->params = *p; c->have_params = true;
     return 0;
 }
