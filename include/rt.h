@@ -186,6 +186,8 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst (default 48)
  *   "node_min"        k_stream: inside a burst the node loop goes on while at least this many lanes hold an internal node (or no
  *                     lane holds a leaf); below it the leaves are served first (default 6; 1 = classic while-while)
+ *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch; a lane that finishes its pixel of one tile moves on to its
+ *                     position in the next tile of the group instead of idling until the tile's slowest pixel is done (default 2)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
  *   "pool_stack", "trav_min_lanes"   k_pool: LDS stack entries per lane; in-flight lanes below which TRAVERSE is left
  *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */

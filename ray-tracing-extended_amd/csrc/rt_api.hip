@@ -89,6 +89,7 @@ struct rt_ctx {
     int auto_choice = -1; double auto_ms[2] = { -1.0, -1.0 };
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
+    int opt_tiles_per_fetch = 2;    // k_stream: measured best (1: 10.24, 2: 10.42, 3: 10.29, 4: 10.06, 8: 9.20 Grays/s)
     int opt_node_min = 6;           // k_stream: measured best 4..8 on the 100k-triangle workload (+7 % over 1)
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 0;          // 1: sort all four children; 0: nearest first only (measured +1 %)
@@ -427,6 +428,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
     A.total_pixels = (unsigned int)ntiles * 64u;
     A.tile_sync = c->opt_tile_sync;
+    A.tiles_per_fetch = std::max(1, std::min(16, c->opt_tiles_per_fetch));
     A.node_min = std::max(1, std::min(64, c->opt_node_min));
     rtk::PoolArgs PA{};
     PA.total_pixels = A.total_pixels;
@@ -774,6 +776,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "tile_w_log2")) { if (value < 0 || value > 6) return fail(c, -2, "tile_w_log2 must be in [0,6]"); c->opt_tile_w_log2 = value; }
     else if (!std::strcmp(name, "tile_lpt")) { c->opt_tile_lpt = value ? 1 : 0; c->tile_order_valid = false; }
     else if (!std::strcmp(name, "frame_batch")) { if (value < 0 || value > 1024) return fail(c, -2, "frame_batch must be in [0,1024]"); c->opt_frame_batch = value; }
+    else if (!std::strcmp(name, "tiles_per_fetch")) { if (value < 1 || value > 16) return fail(c, -2, "tiles_per_fetch must be in [1,16]"); c->opt_tiles_per_fetch = value; }
     else if (!std::strcmp(name, "node_min")) { if (value < 1 || value > 64) return fail(c, -2, "node_min must be in [1,64]"); c->opt_node_min = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;

@@ -24,13 +24,15 @@ struct StreamArgs {
     int shade_threshold;        // lanes waiting for SHADE that trigger it
     unsigned int total_pixels;  // tiles_x * tiles_y * 64 (tile-major enumeration, padded)
     int node_min;               // the node loop of a burst goes on while at least this many lanes hold an internal node (or no lane holds a leaf)
+    int tiles_per_fetch;        // tile_sync: a wave reserves this many consecutive work items at a time; a lane that finishes its
+                                // pixel of one moves on to its position in the next without waiting for the slower lanes
     int tile_sync;              // 1: a wave takes a whole 8x8 tile at a time (coherent lanes), 0: lanes refill pixel by pixel
 };
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -62,36 +64,51 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
     unsigned int wave_fi = 0;           // frame (offset) of the tile this wave is working on
-    unsigned int wave_tile = 0xFFFFFFFFu; unsigned long long wave_t0 = 0;
+    unsigned long long wave_t0 = 0;
+    unsigned int group_base = 0, group_len = 0, kidx = 0;   // items [group_base, group_base + group_len) belong to this wave; kidx: this lane's
+
+    // Give this lane its position's pixel of work item `item` = (frame, tile); false when the tile has no pixel there.
+    auto start_pixel = [&](unsigned int item) -> bool {
+        const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
+        const unsigned int fi = item / ntiles_;
+        unsigned int tile = item - fi * ntiles_;
+        if (F.tile_order) tile = F.tile_order[tile];
+        const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (lane & 7);
+        const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
+        if (!(x < p.width && yy < F.nrows)) return false;
+        px = x; ly = yy; wave_fi = fi;
+        rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)(F.frame + (int)fi) * 719393u;   // :361-362
+        total = rtm::mk(0.f, 0.f, 0.f);
+        sample = 0; live = false;
+        return true;
+    };
 
     for (;;) {
         const int nTrav = __popcll(__ballot(mode == kModeTrav)), nShade = __popcll(__ballot(mode == kModeShade));
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
-            // ---- the whole wave is done with its tile: take the next one (tile-major order)
-            if (F.tile_cost && wave_tile != 0xFFFFFFFFu && lane == 0)
-                atomicAdd(&F.tile_cost[wave_tile], (uint32_t)((__builtin_readcyclecounter() - wave_t0) >> 6));
-            wave_tile = 0xFFFFFFFFu;
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(F.tile_counter, 64u);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const bool batched = F.frames_in_launch > 1;
+            // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
             const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-            unsigned int item = base >> 6;
-            if (item >= ntiles_ * (unsigned)(batched ? F.frames_in_launch : 1)) break;
-            wave_fi = item / ntiles_;                         // work item = (frame, tile), frame-major (as in k_trace)
-            unsigned int tile = item - wave_fi * ntiles_;
-            if (F.tile_order) tile = F.tile_order[tile];
-            wave_tile = tile; wave_t0 = __builtin_readcyclecounter();
-            const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (lane & 7);
-            const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
-            if (x < p.width && yy < F.nrows) {
-                px = x; ly = yy;
-                rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)(F.frame + (int)wave_fi) * 719393u;   // :361-362
-                total = rtm::mk(0.f, 0.f, 0.f);
-                sample = 0; live = false; fresh = true;
-                mode = kModeShade;
+            const unsigned int nitems_ = ntiles_ * (unsigned)(F.frames_in_launch > 1 ? F.frames_in_launch : 1);
+            if (F.tile_cost && group_len != 0 && lane == 0) {
+                const uint32_t share = (uint32_t)(((__builtin_readcyclecounter() - wave_t0) >> 6) / group_len);
+                for (unsigned int k = 0; k < group_len; ++k) {
+                    unsigned int t = (group_base + k) % ntiles_;
+                    if (F.tile_order) t = F.tile_order[t];
+                    atomicAdd(&F.tile_cost[t], share);
+                }
             }
+            const unsigned int K = (unsigned)A.tiles_per_fetch;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(F.tile_counter, 64u * K);
+            base = __builtin_amdgcn_readfirstlane(base);
+            group_base = base >> 6;
+            if (group_base >= nitems_) break;
+            group_len = min(K, nitems_ - group_base);
+            wave_t0 = __builtin_readcyclecounter();
+            kidx = 0;
+            while (kidx < group_len && !start_pixel(group_base + kidx)) ++kidx;
+            if (kidx < group_len) { fresh = true; mode = kModeShade; }
             continue;
         }
 
@@ -172,7 +189,12 @@ __global__ __launch_bounds__(kBlock) void k_stream(DeviceScene S, FrameArgs F, S
                                 F.accum[pi] = acc;
                             }
                             px = -1;
-                            if (A.tile_sync) mode = kModeWait;      // idle until the wave's whole tile is done
+                            if (A.tile_sync) {
+                                // on to this lane's position in the next tile of the wave's group; idle only when the group is done
+                                ++kidx;
+                                while (kidx < group_len && !start_pixel(group_base + kidx)) ++kidx;
+                                if (kidx < group_len) need_ray = true; else mode = kModeWait;
+                            }
                         } else need_ray = true;
                     }
                     live = false;

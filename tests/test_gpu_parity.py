@@ -238,3 +238,20 @@ def test_automatic_kernel_choice_is_transparent(rtx, oracle, tracer):
     assert st["rays"] == cnt["rays"]
     tracer.render_frame(6)                     # decided: single frames keep using the chosen kernel
     assert tracer.stats()["autoKernel"] == st["autoKernel"]
+
+
+@pytest.mark.parametrize("size,k", [((93, 61), 2), ((8, 8), 3), ((200, 9), 4), ((5, 130), 2), ((96, 64), 16)])
+def test_tile_groups_multi_frame(rtx, oracle, tracer, size, k):
+    """k_stream reserving k work items per fetch (lanes flow from one tile of the group to the next without waiting),
+    several frames per launch, partial tiles, fewer items than a group: image and ray count are the oracle's."""
+    b = rtx.scenes.mesh_test_scene(*size).build_buffers()
+    tracer.set_option("tiles_per_fetch", k)
+    try:
+        acc, last = run_gpu(tracer, b, 1, 3, kernel=1)
+        st = tracer.stats()
+    finally:
+        tracer.set_option("tiles_per_fetch", 2)
+    want, want_last, cnt = oracle.render(*b, 1, 3)
+    assert_bitwise(last, want_last, f"{size} k={k}: last frame")
+    assert_bitwise(acc, want, f"{size} k={k}: accum")
+    assert st["rays"] == cnt["rays"]
