@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=3, help="workload: 2 (12 spheres), 3 (~100k tris, headline), 5 (~1M tris, DOF)")
+    ap.add_argument("--config", type=int, default=3, help="workload: 2 (12 spheres), 3 (~100k tris, headline), 4 (same scene at 3840x2160, 12 bounces), 5 (~1M tris, DOF)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--rays", type=int, default=0, help="override rays per pixel per frame (default 64)")
@@ -53,7 +53,7 @@ def parse():
 
 
 def build_workload(rtx, args):
-    gen = {2: rtx.scenes.config2, 3: rtx.scenes.config3, 5: rtx.scenes.config5}[args.config]
+    gen = {2: rtx.scenes.config2, 3: rtx.scenes.config3, 4: rtx.scenes.config4, 5: rtx.scenes.config5}[args.config]
     mgr = gen(args.width, args.height) if args.width and args.height else gen()
     if args.rays:
         mgr.numRaysPerPixel = args.rays
@@ -231,6 +231,7 @@ def main():
     if rank != 0:
         return
     names = {2: "configs[1]: 12 spheres Cornell style", 3: "configs[2]: Chess pieces x17 (100,440 triangles, BVH4)",
+             4: "configs[3]: Chess pieces x17 (100,440 triangles, BVH4), 4K",
              5: "configs[4]: Chess pieces x170 (1,004,364 triangles, BVH4), DOF on"}
     out = {
         "metric": "Mrays/s", "value": round(total_rays / wall / 1e6, 2), "unit": "Mrays/s",
