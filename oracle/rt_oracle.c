@@ -39,6 +39,7 @@
 #include "rt_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -312,7 +313,117 @@ typedef struct {
     const rt_triangle* tris;     int nt;
     const rt_meshinfo* mi;       int nm;
     int mode;
+    const struct oaccel* accel;     /* non-NULL: triangles are found through the oracle's own search tree (below) */
 } scene_t;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Optional search tree of the ORACLE (orc_set_accel(1)).  It is not part of the reference and not the
+ * product's BVH: a plain binary tree (spatial-median splits, leaves <= 4 references) over the (chunk,
+ * triangle) references in the order the reference's loop visits them, used only so that the checker can
+ * finish full-size images.  It must return exactly what the linear loop of calculate_ray_collision
+ * returns: the minimum RayTriangle dst, ties to the reference visited first, FLAT_CHUNKS candidates only
+ * from chunks whose literal RayBoundingBox passes; tests/test_oracle_cpu.py checks tree == loop bit for
+ * bit.  Box tests are done in double on boxes padded 10x wider than the product pads its own, and the
+ * distance prune keeps a 1 % + 1e-2 slack, so the tree is more conservative than the thing it checks. */
+typedef struct { uint32_t m, tri, seq; } oref;
+typedef struct { float lo[3], hi[3]; int32_t left, right; /* right < 0: leaf, refs [left, left + ~right) */ } onode;
+typedef struct oaccel { onode* nodes; int nnodes; oref* refs; uint32_t nrefs; } oaccel;
+static int g_accel = 0;
+void orc_set_accel(int on) { g_accel = on; }
+
+static void ref_box(const scene_t* sc, const oref* r, float pad_g, float lo[3], float hi[3])
+{
+    const rt_triangle* t = &sc->tris[r->tri];
+    for (int a = 0; a < 3; a++) {
+        float p0 = t->posA[a], p1 = t->posB[a], p2 = t->posC[a];
+        float mn = fminf(p0, fminf(p1, p2)), mx = fmaxf(p0, fmaxf(p1, p2));
+        float pad = 3e-4f * fmaxf(fabsf(mn), fabsf(mx)) + pad_g;
+        lo[a] = mn - pad; hi[a] = mx + pad;
+    }
+}
+
+static oaccel* accel_build(const scene_t* sc)
+{
+    uint64_t n = 0;
+    for (int m = 0; m < sc->nm; m++) n += sc->mi[m].numTriangles;
+    oaccel* A = (oaccel*)calloc(1, sizeof *A);
+    A->nrefs = (uint32_t)n;
+    A->refs = (oref*)malloc((n ? n : 1) * sizeof(oref));
+    A->nodes = (onode*)malloc((2 * n + 1) * sizeof(onode));
+    float G = fmaxf(fabsf(sc->p->camLocalToWorld[3]), fmaxf(fabsf(sc->p->camLocalToWorld[7]), fabsf(sc->p->camLocalToWorld[11])));
+    uint32_t k = 0;
+    for (int m = 0; m < sc->nm; m++)
+        for (uint32_t i = 0; i < sc->mi[m].numTriangles; i++, k++) {
+            oref r = { (uint32_t)m, sc->mi[m].firstTriangleIndex + i, k };
+            A->refs[k] = r;
+            const rt_triangle* t = &sc->tris[r.tri];
+            for (int a = 0; a < 3; a++) {
+                float v = fmaxf(fabsf(t->posA[a]), fmaxf(fabsf(t->posB[a]), fabsf(t->posC[a])));
+                if (v > G && v < INFINITY) G = v;
+            }
+        }
+    const float pad_g = 2e-5f * G;
+    if (n == 0) { A->nnodes = 0; return A; }
+    float* cen = (float*)malloc(n * 3 * sizeof(float));      /* centroid per seq */
+    for (uint32_t i = 0; i < n; i++) {
+        const rt_triangle* t = &sc->tris[A->refs[i].tri];
+        for (int a = 0; a < 3; a++) cen[3 * i + a] = (t->posA[a] + t->posB[a] + t->posC[a]) * (1.0f / 3.0f);
+    }
+    typedef struct { int node; uint32_t first, count; } job;
+    job* stack = (job*)malloc(128 * sizeof(job)); int sp = 0, cap = 128;
+    A->nnodes = 1;
+    stack[sp++] = (job){ 0, 0, (uint32_t)n };
+    while (sp) {
+        job j = stack[--sp];
+        onode* nd = &A->nodes[j.node];
+        float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int a = 0; a < 3; a++) { nd->lo[a] = INFINITY; nd->hi[a] = -INFINITY; }
+        for (uint32_t i = j.first; i < j.first + j.count; i++) {
+            float lo[3], hi[3]; ref_box(sc, &A->refs[i], pad_g, lo, hi);
+            const float* c = &cen[3 * A->refs[i].seq];
+            for (int a = 0; a < 3; a++) {
+                if (lo[a] < nd->lo[a]) nd->lo[a] = lo[a];
+                if (hi[a] > nd->hi[a]) nd->hi[a] = hi[a];
+                if (c[a] < clo[a]) clo[a] = c[a];
+                if (c[a] > chi[a]) chi[a] = c[a];
+            }
+        }
+        if (j.count <= 4) { nd->left = (int32_t)j.first; nd->right = ~(int32_t)j.count; continue; }
+        int ax = 0;
+        if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+        if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+        float mid = 0.5f * (clo[ax] + chi[ax]);
+        uint32_t lo_i = j.first, hi_i = j.first + j.count;
+        while (lo_i < hi_i) {
+            if (cen[3 * A->refs[lo_i].seq + ax] < mid) lo_i++;
+            else { oref t = A->refs[lo_i]; A->refs[lo_i] = A->refs[--hi_i]; A->refs[hi_i] = t; }
+        }
+        uint32_t nl = lo_i - j.first;
+        if (nl == 0 || nl == j.count) nl = j.count / 2;       /* coincident centroids (or NaN): split by count */
+        int l = A->nnodes, r = A->nnodes + 1; A->nnodes += 2;
+        nd->left = l; nd->right = r;
+        if (sp + 2 > cap) { cap *= 2; stack = (job*)realloc(stack, cap * sizeof(job)); }
+        stack[sp++] = (job){ l, j.first, nl };
+        stack[sp++] = (job){ r, j.first + nl, j.count - nl };
+    }
+    free(stack); free(cen);
+    return A;
+}
+static void accel_free(oaccel* A) { if (A) { free(A->nodes); free(A->refs); free(A); } }
+
+/* conservative slab test in double; a zero direction component constrains only by containment */
+static inline int accel_box(const onode* nd, const double o[3], const double d[3], const double inv[3], double limit)
+{
+    double tn = -INFINITY, tf = INFINITY;
+    for (int a = 0; a < 3; a++) {
+        if (d[a] == 0.0) { if (o[a] < nd->lo[a] || o[a] > nd->hi[a]) return 0; continue; }
+        double t0 = (nd->lo[a] - o[a]) * inv[a], t1 = (nd->hi[a] - o[a]) * inv[a];
+        if (t0 > t1) { double t = t0; t0 = t1; t1 = t; }
+        if (t0 > tn) tn = t0;
+        if (t1 < tf) tf = t1;
+    }
+    return tn <= tf && tf >= 0.0 && tn <= limit;
+}
 
 /* CalculateRayCollision :256-297 */
 static hit_t calculate_ray_collision(const scene_t* sc, v3 o, v3 d, orc_counts* cnt)
@@ -332,6 +443,46 @@ static hit_t calculate_ray_collision(const scene_t* sc, v3 o, v3 d, orc_counts* 
             closest.normal = v_normalize(v_sub(closest.hitPoint, v_load(s->position)));
             closest.material = &s->material;
         }
+    }
+    if (sc->accel) {
+        const oaccel* A = sc->accel;
+        const double od[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+        const double inv[3] = { 1.0 / dd[0], 1.0 / dd[1], 1.0 / dd[2] };
+        int nan_ray = !(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
+        uint32_t best_seq = 0; int best_is_tri = 0;
+        int32_t stack[256]; int sp = 0;
+        if (A->nnodes && !nan_ray) stack[sp++] = 0;     /* a NaN ray fails every RayTriangle comparison */
+        while (sp) {
+            const onode* nd = &A->nodes[stack[--sp]];
+            double limit = (closest.dst == INFINITY) ? INFINITY : (double)closest.dst * 1.01 + 1e-2;
+            cnt->boxTests++;
+            if (!accel_box(nd, od, dd, inv, limit)) continue;
+            if (nd->right >= 0) {
+                if (sp + 2 > 256) { fprintf(stderr, "oracle: search-tree stack overflow\n"); abort(); }
+                stack[sp++] = nd->left; stack[sp++] = nd->right; continue;
+            }
+            for (int32_t i = nd->left; i < nd->left + ~nd->right; i++) {
+                const oref* r = &A->refs[i];
+                const rt_triangle* t = &sc->tris[r->tri];
+                float dst, u, v, w;
+                cnt->triTests++;
+                if (!ray_triangle(o, d, t, &dst, &u, &v, &w)) continue;
+                /* the loop's `dst < closest.dst` with first-visited-wins on equal dst (spheres are visited before) */
+                if (!(dst < closest.dst || (dst == closest.dst && best_is_tri && r->seq < best_seq))) continue;
+                const rt_meshinfo* mi = &sc->mi[r->m];
+                if (sc->mode == RT_INTERSECT_FLAT_CHUNKS && !ray_bounding_box(o, d, mi->boundsMin, mi->boundsMax)) continue;
+                closest.didHit = 1;
+                closest.dst = dst;
+                closest.hitPoint = v_add(o, v_scale(d, dst));
+                v3 nn = v_add(v_add(v_scale(v_load(t->normalA), w), v_scale(v_load(t->normalB), u)),
+                              v_scale(v_load(t->normalC), v));
+                closest.normal = v_normalize(nn);
+                closest.material = &mi->material;
+                best_seq = r->seq; best_is_tri = 1;
+            }
+        }
+        if (closest.didHit) cnt->hits++;
+        return closest;
     }
     for (int m = 0; m < sc->nm; m++) {
         const rt_meshinfo* mi = &sc->mi[m];
@@ -470,7 +621,9 @@ int orc_render_frame(const rt_params* params,
     if (x0 < 0 || y0 < 0 || x1 > params->width || y1 > params->height || x0 > x1 || y0 > y1) return -2;
     for (int m = 0; m < nm; m++)
         if ((uint64_t)meshinfo[m].firstTriangleIndex + meshinfo[m].numTriangles > (uint64_t)nt) return -3;
-    scene_t sc = { params, spheres, ns, tris, nt, meshinfo, nm, params->intersectMode };
+    scene_t sc = { params, spheres, ns, tris, nt, meshinfo, nm, params->intersectMode, NULL };
+    oaccel* accel = g_accel ? accel_build(&sc) : NULL;
+    sc.accel = accel;
     orc_counts tot; memset(&tot, 0, sizeof tot);
     int cw = x1 - x0;
 #ifdef _OPENMP
@@ -492,6 +645,7 @@ int orc_render_frame(const rt_params* params,
             tot.triTests += loc.triTests; tot.hits += loc.hits;
         }
     }
+    accel_free(accel);
     if (counts) *counts = tot;
     return 0;
 }

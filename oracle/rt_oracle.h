@@ -31,6 +31,11 @@ int orc_render_frame(const rt_params* params,
                      int frame, int x0, int y0, int x1, int y1,
                      float* out_rgba, int nthreads, orc_counts* counts);
 
+/* on != 0: later orc_render_frame calls find triangles through the oracle's own search tree instead of the linear
+ * loop — same result bit for bit (tests/test_oracle_cpu.py), fast enough for full-size images.  In that mode
+ * boxTests / triTests count the tree's work, not the reference loop's. */
+void orc_set_accel(int on);
+
 /* Accumulate.shader:43-54 applied in place to `accum` (n_floats = pixels*4). */
 void orc_accumulate(float* accum, const float* cur, size_t n_floats, int frame);
 

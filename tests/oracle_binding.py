@@ -46,9 +46,14 @@ class Oracle:
         L.orc_display_srgb8.restype = None
         L.orc_display_srgb8.argtypes = [POINTER(c_float), c_void_p, c_size_t]
         L.orc_hw_threads.restype = c_int
+        L.orc_set_accel.restype = None
+        L.orc_set_accel.argtypes = [c_int]
 
-    def render_frame(self, params, spheres, tris, meshinfo, frame, rect=None, mode=None, nthreads=0):
-        """Returns (image[h, w, 4] float32, counts dict) for pixel rect (x0, y0, x1, y1) of the full image."""
+    def render_frame(self, params, spheres, tris, meshinfo, frame, rect=None, mode=None, nthreads=0, accel=False):
+        """Returns (image[h, w, 4] float32, counts dict) for pixel rect (x0, y0, x1, y1) of the full image.
+        accel=True: the oracle finds triangles through its own search tree (same image bit for bit, tested; the
+        box/triangle counters then describe the tree)."""
+        self.lib.orc_set_accel(1 if accel else 0)
         r = self.rtx
         p = np.array(params, dtype=r.PARAMS).reshape(()).copy()
         if mode is not None:
@@ -78,12 +83,12 @@ class Oracle:
         self.lib.orc_display_srgb8(a.ctypes.data_as(POINTER(c_float)), out.ctypes.data_as(c_void_p), out.size)
         return out.view(np.uint8).reshape(a.shape[:-1] + (4,))
 
-    def render(self, params, spheres, tris, meshinfo, first_frame, n_frames, rect=None, mode=None):
+    def render(self, params, spheres, tris, meshinfo, first_frame, n_frames, rect=None, mode=None, accel=False):
         """Trace + accumulate n_frames frames (OnRenderImage order); returns (accum, last_frame, counts)."""
         acc = None
         total = None
         for f in range(first_frame, first_frame + n_frames):
-            cur, cnt = self.render_frame(params, spheres, tris, meshinfo, f, rect, mode)
+            cur, cnt = self.render_frame(params, spheres, tris, meshinfo, f, rect, mode, accel=accel)
             if acc is None:
                 acc = np.zeros_like(cur)
             self.accumulate(acc, cur, f)

@@ -139,3 +139,46 @@ def test_full_size_headline_frame_bvh_equals_flat_loop(rtx, tracer):
     assert_bitwise(stream, flat, "k_stream vs flat loop, 1080p")
     assert_bitwise(trace, flat, "k_trace vs flat loop, 1080p")
     assert rays_stream == rays_trace == rays_flat > 4_000_000
+
+
+# ---- full-size frames against the oracle (through the oracle's own search tree: tests/test_oracle_cpu.py shows tree == loop) ----
+
+def _full_frame_vs_oracle(oracle, tracer, m, what, mode=0, frame=0, kernel=1):
+    b = m.build_buffers()
+    _, got = run_gpu(tracer, b, frame, 1, mode=mode, kernel=kernel)
+    rays_gpu = tracer.stats()["rays"]
+    want, cnt = oracle.render_frame(*b, frame, mode=mode, accel=True)
+    assert_bitwise(got, want, what)
+    return rays_gpu, cnt
+
+
+def test_full_size_headline_frame_vs_oracle(rtx, oracle, tracer):
+    """BASELINE's headline configuration exactly as benchmarked (1920x1080, 100,440 triangles, 64 rays per pixel, 8 bounces):
+    every one of the 2,073,600 pixels of a frame equals the oracle's, and so does the number of rays traced (~2.4e8)."""
+    m = rtx.scenes.config3()
+    assert (m.numRaysPerPixel, m.maxBounceCount) == (64, 8)
+    rays, cnt = _full_frame_vs_oracle(oracle, tracer, m, "config3 1080p x64 vs oracle", frame=5)
+    assert rays == cnt["rays"] > 200_000_000
+
+
+@pytest.mark.parametrize("name", ["Chess", "Knight", "Reflective_Balls", "Balls_Outdoors"])
+def test_reference_scene_full_hd_vs_oracle(rtx, oracle, tracer, name):
+    """The reference's own scenes at 1920x1080 with their serialized settings' bounce count, 1 ray per pixel, frame 3."""
+    from rtx_amd import unity_scene
+    m = unity_scene.load_scene_npz(os.path.join(GOLDEN, "scenes", name + ".npz"), 1920, 1080)
+    m.numRaysPerPixel = 1
+    _full_frame_vs_oracle(oracle, tracer, m, f"{name} 1080p vs oracle", frame=3, kernel=-1)
+
+
+def test_million_triangle_frame_vs_oracle(rtx, oracle, tracer):
+    """configs[4] (1,004,364 triangles, depth of field) at 960x540, 1 ray per pixel, whole frame."""
+    m = rtx.scenes.config5(960, 540)
+    m.numRaysPerPixel = 1
+    _full_frame_vs_oracle(oracle, tracer, m, "config5 960x540 vs oracle")
+
+
+def test_4k_frame_vs_oracle_brute_mode(rtx, oracle, tracer):
+    """configs[3] (3840x2160, 12 bounces), 1 ray per pixel, BRUTE intersect mode (no chunk cull), whole frame."""
+    m = rtx.scenes.config4()
+    m.numRaysPerPixel = 1
+    _full_frame_vs_oracle(oracle, tracer, m, "config4 4K vs oracle", mode=1)

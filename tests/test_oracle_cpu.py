@@ -131,6 +131,48 @@ def test_flat_chunks_vs_brute_on_reference_scene(rtx, oracle):
     assert cf["boxTests"] == 39 * cf["rays"] and cb["boxTests"] == 0 and cb["triTests"] == 530 * cb["rays"]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_oracle_search_tree_returns_the_loops_image(rtx, oracle, mode):
+    """orc_set_accel: the oracle's own search tree (used to check full-size frames) must give the literal loop's image
+    bit for bit — spheres + meshes, the Knight scene (530-triangle chunks) and a window of the 100k-triangle scene."""
+    from rtx_amd import unity_scene
+    cases = [(rtx.scenes.mesh_test_scene(64, 40), None)]
+    k = unity_scene.load_scene_npz(os.path.join(GOLDEN, "scenes", "Knight.npz"), 64, 36)
+    k.numRaysPerPixel, k.maxBounceCount = 2, 3
+    cases.append((k, None))
+    c3 = rtx.scenes.config3(480, 270)
+    c3.numRaysPerPixel, c3.maxBounceCount = 2, 4
+    cases.append((c3, (216, 100, 240, 108) if mode == 1 else (216, 100, 264, 116)))
+    for m, rect in cases:
+        b = m.build_buffers()
+        loop, cl = oracle.render_frame(*b, 1, rect, mode=mode)
+        tree, ct = oracle.render_frame(*b, 1, rect, mode=mode, accel=True)
+        _assert_bits(tree, loop, "search tree vs loop")
+        assert (cl["rays"], cl["hits"], cl["sphereTests"]) == (ct["rays"], ct["hits"], ct["sphereTests"])
+
+
+def test_oracle_search_tree_tie_break_and_degenerate_input(rtx, oracle):
+    """Coincident triangles (equal dst: the first in buffer order wins, RayTracing.shader:287 strict <), zero-area and NaN
+    triangles, and an empty scene go through the tree like through the loop."""
+    m = rtx.scenes.mesh_test_scene(40, 24)
+    p, s, t, mi = m.build_buffers()
+    t = np.concatenate([t, t[:40], t[:40]]).copy()            # two more copies of the first 40 triangles, later in the buffer
+    extra = np.zeros(2, mi.dtype)
+    extra[:] = mi[0]
+    extra["firstTriangleIndex"] = [len(t) - 80, len(t) - 40]
+    extra["numTriangles"] = 40
+    extra[1]["material"]["colour"] = (0.1, 0.9, 0.1, 1.0)     # visible if the tie went to the later copy
+    mi2 = np.concatenate([mi, extra])
+    t[-1]["posB"] = t[-1]["posA"]                             # zero area
+    t[-2]["posC"] = (np.nan, 0, 0)
+    loop, _ = oracle.render_frame(p, s, t, mi2, 0, mode=1)
+    tree, _ = oracle.render_frame(p, s, t, mi2, 0, mode=1, accel=True)
+    _assert_bits(tree, loop, "ties / degenerate")
+    none, _ = oracle.render_frame(p, s[:0], t[:0], mi[:0], 0, accel=True)
+    ref, _ = oracle.render_frame(p, s[:0], t[:0], mi[:0], 0)
+    _assert_bits(none, ref, "empty scene")
+
+
 def test_display_srgb8_known_values(oracle):
     """sRGB transfer: 0 -> 0, 1 -> 255, 0.0031308 -> 10 (linear segment), 0.5 -> 188, 0.2159 -> 128; >1 and NaN clamp."""
     px = np.array([[0.0, 1.0, 0.0031308, 1.0], [0.5, 0.2159, 2.0, 0.5], [np.nan, -1.0, 0.05, 1.0]], np.float32)
