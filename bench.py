@@ -199,6 +199,12 @@ def main():
     else:
         total_rays, wall = rays[0].item(), dt
     kernel_ms_rank0 = st["totalKernelMs"]
+    busy = [round(kernel_ms_rank0, 3)]
+    if dist is not None:                       # per-GPU busy time (load balance of the decomposition)
+        mine = torch.tensor([st["totalKernelMs"]], dtype=torch.float64, device=comm_dev)
+        allb = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
+        busy = [round(b.item(), 3) for b in allb]
 
     # ---- roofline (rank 0's strip): counting build of the same kernel over the same K frames, untimed
     roofline = None
@@ -236,6 +242,9 @@ def main():
                                                zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseLanes"], sc["phaseExecs"])},
                     "phase_wave_execs_per_ray": {n: round(e * 64 / max(sc["rays"], 1), 2) for n, e in
                                                  zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseExecs"])},
+                    "primitive_tests_per_s": {"box": round(sc["nodeVisits"] * 4 / (kernel_ms_rank0 / 1e3), 0),
+                                              "triangle": round(sc["triTests"] / (kernel_ms_rank0 / 1e3), 0),
+                                              "sphere": round(sc["sphereTests"] / (kernel_ms_rank0 / 1e3), 0)},
                     "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]},
                     "limiter": "VALU issue (cache-resident working set): see pmc", "pmc": pmc_extra}
     cpu = None
@@ -261,7 +270,8 @@ def main():
                    "decomposition": (f"{world} ranks, " + ("interleaved 8-row bands" if banded else "contiguous row strips")
                                      + " + one RCCL gather") if world > 1 else "single GPU",
                    "rays_per_frame": int(total_rays / max(args.steps, 1)),
-                   "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres))},
+                   "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres)),
+                   "per_gpu_kernel_ms": busy},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

@@ -222,3 +222,30 @@ def test_cpp_host_loads_the_reference_scenes_unchanged():
         for g, w in zip(got, want):
             assert g.tobytes() == w.tobytes(), p
         cpp.close()
+
+
+def test_exr_writer_layout_and_round_trip(rtx, tmp_path):
+    """write_exr: OpenEXR magic 76 2f 31 01, version 2, uncompressed scanline blocks of A,B,G,R planes, top row first; the
+    float file reads back bit for bit (including inf / NaN), the half file within half precision."""
+    import struct
+    rng = np.random.default_rng(3)
+    img = rng.random((6, 9, 4), dtype=np.float32)
+    img[0, 0, 0], img[5, 8, 2] = np.inf, np.nan
+    f32, f16 = str(tmp_path / "a.exr"), str(tmp_path / "h.exr")
+    rtx.imageio.write_exr(f32, img)
+    rtx.imageio.write_exr(f16, img, half=True)
+    raw = open(f32, "rb").read()
+    assert raw[:8] == bytes([0x76, 0x2F, 0x31, 0x01, 2, 0, 0, 0])
+    assert raw[8:17] == b"channels\0" and b"compression\0compression\0\x01\0\0\0\0" in raw
+    hdr_end = raw.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+    offs = np.frombuffer(raw, "<u8", 6, hdr_end)
+    assert offs[0] == hdr_end + 48 and (np.diff(offs) == 8 + 9 * 16).all() and len(raw) == offs[-1] + 8 + 9 * 16
+    y0, nbytes = struct.unpack_from("<ii", raw, int(offs[0]))
+    assert (y0, nbytes) == (0, 9 * 16)
+    top_alpha = np.frombuffer(raw, "<f4", 9, int(offs[0]) + 8)
+    assert (top_alpha == img[5, :, 3]).all()                       # first block = top row = the tracer's last row; plane A first
+    back = rtx.imageio.read_exr(f32)
+    assert (back.view(np.uint32) == img.view(np.uint32)).all()
+    h = rtx.imageio.read_exr(f16)
+    fin = np.isfinite(img)
+    assert np.abs(h[fin] - img[fin]).max() < 5e-4 and np.isinf(h[0, 0, 0]) and np.isnan(h[5, 8, 2])
