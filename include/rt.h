@@ -176,8 +176,9 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
 /* Tuning knobs; the image never depends on them (tested bitwise).
  *   "kernel"          -1 = automatic (default): the first frames after a scene / camera change time k_trace and k_stream on
  *                     ordinary frames of the render and the faster one takes the rest; 0 = tile-per-wave megakernel k_trace,
- *                     1 = k_stream (resumable traversal, stragglers deferred), 2 = k_pool (pixel slots in LDS, in-wave
- *                     ballot/prefix-sum compaction)
+ *                     1 = k_stream (resumable traversal, stragglers deferred), 2 = k_pool (128 pixel slots per wave in LDS,
+ *                     in-wave ballot/prefix-sum compaction), 3 = k_wave (256 pixel slots per wave, path state in global
+ *                     memory, phases on compacted slot lists); 2 and 3 are measured alternatives, never picked automatically
  *   "max_leaf"        triangles per BVH leaf, 1..4 (default 2)
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order
@@ -190,6 +191,8 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     position in the next tile of the group instead of idling until the tile's slowest pixel is done (default 2)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
  *   "pool_stack", "trav_min_lanes"   k_pool: LDS stack entries per lane; in-flight lanes below which TRAVERSE is left
+ *   "refill_min", "wave_trav_min", "wave_node_min"   k_wave: idle lanes that trigger a refill from the pending list (16);
+ *                     in-flight lanes below which TRAVERSE is left once the list is dry (24); node-loop hand-over (24)
  *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);
 

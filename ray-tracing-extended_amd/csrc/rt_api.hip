@@ -16,6 +16,7 @@
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
 #include "rt_pool.hpp"
+#include "rt_wave.hpp"
 #include "rt_geom.hpp"
 
 namespace {
@@ -101,6 +102,10 @@ struct rt_ctx {
     int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
     int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
     DevBuf<uint32_t> d_gstack;
+    DevBuf<uint32_t> d_wave_state;     // k_wave: path state of every wave's pixel slots
+    int opt_refill_min = 16;        // k_wave: idle lanes that trigger a refill from the pending list
+    int opt_wave_node_min = 24;     // k_wave: its node loop hands over to the leaves below this many descending lanes
+    int opt_wave_trav_min = 24;     // k_wave: leave TRAVERSE below this many in-flight lanes once the pending list is dry
     rt_stats stats{};
 };
 
@@ -357,7 +362,7 @@ int ensure_targets(rt_ctx* c)
 
 enum class Variant { Fast, Counting, Flat };
 
-// One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream, 2 k_pool).
+// One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream, 2 k_pool, 3 k_wave).
 int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int kernel)
 {
     if (!c) return -1;
@@ -397,8 +402,11 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const bool stream = !philox && kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
     const bool pooled = !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
-    F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // k_stream's branch-free push writes up to 3 slots past the top
-    const bool tile_kernel = !stream && !pooled && var != Variant::Flat;   // k_trace, PCG or Philox
+    const bool waved = !philox && kernel == 3 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
+                       && c->params.numRaysPerPixel <= rtk::wv::kMaxSamples && c->params.maxBounceCount <= rtk::wv::kMaxBounce
+                       && c->target_w <= 65535 && c->target_rows <= 65535;
+    F.stack_cap = std::max(1, c->bvh.maxStack) + (stream || waved ? 3 : 0);    // the branch-free push writes up to 3 slots past the top
+    const bool tile_kernel = !stream && !pooled && !waved && var != Variant::Flat;   // k_trace, PCG or Philox
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     F.full_sort = c->opt_full_sort;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
@@ -407,10 +415,12 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const int pool_cap = std::max(1, std::min(c->opt_pool_stack, std::max(1, c->bvh.maxStack)));
     const size_t lds = var == Variant::Flat ? 0
                      : pooled ? (size_t)rtk::pool::wave_dwords(pool_cap) * sizeof(uint32_t) * rtk::kWavesPerBlock
+                     : waved ? rtk::wv::wave_lds_bytes(F.stack_cap) * rtk::kWavesPerBlock
                               : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
     if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
                    : pooled ? (var == Variant::Fast ? (const void*)rtk::k_pool<false> : (const void*)rtk::k_pool<true>)
+                   : waved ? (var == Variant::Fast ? (const void*)rtk::k_wave<false> : (const void*)rtk::k_wave<true>)
                    : stream ? (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>)
                    : philox ? (var == Variant::Fast ? (const void*)rtk::k_trace<false, false, true> : (const void*)rtk::k_trace<true, false, true>)
                             : (var == Variant::Fast ? (const void*)rtk::k_trace<false, false> : (const void*)rtk::k_trace<true, false>);
@@ -420,7 +430,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (per_cu < 1) return fail(c, -7, "kernel does not fit a CU (LDS %zu B)", lds);
     const int ntiles = F.tiles_x * F.tiles_y;
     // k_pool waves own 128 pixel slots each: two tiles' worth
+    // ... and k_wave waves 256: four tiles' worth (of any frame of the launch)
+    const int frames_hint = waved ? std::max(1, std::min(n_frames, 8)) : 1;
     const int want = pooled ? (ntiles + 2 * rtk::kWavesPerBlock - 1) / (2 * rtk::kWavesPerBlock)
+                   : waved ? (int)(((size_t)ntiles * frames_hint + 4 * rtk::kWavesPerBlock - 1) / (4 * rtk::kWavesPerBlock))
                             : (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
     if (c->opt_blocks_per_cu > 0) per_cu = std::min(per_cu, c->opt_blocks_per_cu);
     const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
@@ -435,6 +448,14 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     PA.trav_min_lanes = std::max(1, std::min(64, c->opt_trav_min_lanes));
     PA.lds_stack_cap = pool_cap;
     PA.gstack_stride = (unsigned int)grid * rtk::kBlock;
+    rtk::WaveArgs WA{};
+    if (waved) {
+        RT_HIP(c, c->d_wave_state.ensure((size_t)grid * rtk::kWavesPerBlock * rtk::wv::wave_state_dwords()));
+        WA.state = c->d_wave_state.p;
+        WA.refill_min = std::max(1, std::min(64, c->opt_refill_min));
+        WA.trav_min_lanes = std::max(1, std::min(64, c->opt_wave_trav_min));
+        WA.node_min = std::max(1, std::min(64, c->opt_wave_node_min));
+    }
     if (tile_kernel && c->bvh.maxStack > F.stack_cap) {
         RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - F.stack_cap) * PA.gstack_stride));
         F.gstack = c->d_gstack.p; F.gstack_stride = PA.gstack_stride;
@@ -448,22 +469,22 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     // frames as well — what matters when a rank's strip has about as many tiles as the chip has wave slots.
     int batch = 1;
     const bool stream_tiles = stream && c->opt_tile_sync;        // k_stream taking whole tiles: same (frame, tile) items as k_trace
-    if ((tile_kernel || stream_tiles) && n_frames > 1 && c->opt_frame_batch != 1) {
+    if ((tile_kernel || stream_tiles || waved) && n_frames > 1 && c->opt_frame_batch != 1) {
         const size_t budget = (size_t)1 << 30;                                  // <= 1 GiB of per-frame outputs
         const size_t per_frame = c->target_pixels * sizeof(float4);
         batch = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, budget / per_frame));
         if (c->opt_frame_batch > 1) batch = std::min(batch, c->opt_frame_batch);
-        batch = std::min(batch, 256);
+        batch = std::min(batch, waved ? rtk::wv::kMaxFrames : 256);
         if (batch > 1) RT_HIP(c, c->d_batch.ensure((size_t)batch * c->target_pixels));
     }
     // LPT scheduling of the persistent waves: a launch records every tile's cost; the next ones hand tiles out costliest
     // first, so the end of a launch is filled with cheap tiles instead of waiting for a few expensive ones.
-    const bool lpt = (tile_kernel || (stream && c->opt_tile_sync)) && c->opt_tile_lpt && ntiles > 1;
+    const bool lpt = (tile_kernel || (stream && c->opt_tile_sync) || waved) && c->opt_tile_lpt && ntiles > 1;
     bool record_costs = false;
     if (lpt) {
         if (c->tile_order_n != ntiles) { c->tile_order_valid = false; c->tile_order_n = ntiles; }
         RT_HIP(c, c->d_tile_cost.ensure(ntiles)); RT_HIP(c, c->d_tile_order.ensure(ntiles));
-        if (!c->tile_order_valid || c->tile_order_stale) {
+        if ((!c->tile_order_valid || c->tile_order_stale) && !waved) {       // k_wave mixes tiles in a wave: it uses an order, it cannot measure one
             record_costs = true;
             RT_HIP(c, hipMemsetAsync(c->d_tile_cost.p, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
         }
@@ -478,8 +499,12 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
         F.out_frame = nb > 1 ? c->d_batch.p : c->d_frame.p;
         RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+        WA.total_pixels = (unsigned int)ntiles * 64u * (unsigned int)nb;
         if (var == Variant::Flat) hipLaunchKernelGGL((rtk::k_trace<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
-        else if (pooled) {
+        else if (waved) {
+            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_wave<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, WA);
+            else                      hipLaunchKernelGGL((rtk::k_wave<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, WA);
+        } else if (pooled) {
             if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_pool<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
             else                      hipLaunchKernelGGL((rtk::k_pool<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
         } else if (stream) {
@@ -541,7 +566,25 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     if (!c) return -1;
     const bool eligible = c->opt_kernel < 0 && var != Variant::Flat && c->have_params && c->params.rngMode == RT_RNG_PCG
                           && c->params.numRaysPerPixel >= 1;
-    if (!eligible) return launch_frames_k(c, first_frame, n_frames, var, c->opt_kernel < 0 ? 0 : c->opt_kernel);
+    if (!eligible) {
+        const int kernel = c->opt_kernel < 0 ? 0 : c->opt_kernel;
+        // k_wave hands tiles out costliest first but cannot measure a tile's cost itself: k_trace traces the first frame
+        // after a scene / target change and records the costs (an ordinary frame of the render, nothing is traced twice)
+        if (kernel == 3 && var != Variant::Flat && c->opt_tile_lpt && n_frames > 1 && c->have_params
+            && (c->scene_dirty || !c->tile_order_valid || c->tile_order_stale)) {
+            int r = launch_frames_k(c, first_frame, 1, var, 0);
+            if (r) return r;
+            const rt_stats a = c->stats;
+            r = launch_frames_k(c, first_frame + 1, n_frames - 1, var, kernel);
+            if (r) return r;
+            c->stats.rays += a.rays; c->stats.sphereTests += a.sphereTests; c->stats.nodeVisits += a.nodeVisits;
+            c->stats.triTests += a.triTests; c->stats.hits += a.hits;
+            for (int k = 0; k < 5; ++k) { c->stats.phaseLanes[k] += a.phaseLanes[k]; c->stats.phaseExecs[k] += a.phaseExecs[k]; }
+            c->stats.lastKernelMs += a.lastKernelMs;
+            return 0;
+        }
+        return launch_frames_k(c, first_frame, n_frames, var, kernel);
+    }
     if (c->auto_choice >= 0 && !c->scene_dirty && c->tile_order_valid)
         return launch_frames_k(c, first_frame, n_frames, var, c->auto_choice);
 
@@ -649,7 +692,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -767,8 +810,11 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
 {
     if (!c) return -1;
     if (!name) return fail(c, -2, "null option name");
-    if (!std::strcmp(name, "kernel")) { if (value < -1 || value > 2) return fail(c, -2, "kernel must be -1 (auto), 0, 1 or 2"); c->opt_kernel = value; }
+    if (!std::strcmp(name, "kernel")) { if (value < -1 || value > 3) return fail(c, -2, "kernel must be -1 (auto), 0, 1, 2 or 3"); c->opt_kernel = value; }
     else if (!std::strcmp(name, "pool_stack")) { if (value < 1 || value > 64) return fail(c, -2, "pool_stack must be in [1,64]"); c->opt_pool_stack = value; }
+    else if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) return fail(c, -2, "refill_min must be in [1,64]"); c->opt_refill_min = value; }
+    else if (!std::strcmp(name, "wave_node_min")) { if (value < 1 || value > 64) return fail(c, -2, "wave_node_min must be in [1,64]"); c->opt_wave_node_min = value; }
+    else if (!std::strcmp(name, "wave_trav_min")) { if (value < 1 || value > 64) return fail(c, -2, "wave_trav_min must be in [1,64]"); c->opt_wave_trav_min = value; }
     else if (!std::strcmp(name, "trav_min_lanes")) { if (value < 1 || value > 64) return fail(c, -2, "trav_min_lanes must be in [1,64]"); c->opt_trav_min_lanes = value; }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }

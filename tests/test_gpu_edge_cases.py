@@ -9,7 +9,7 @@ from test_gpu_parity import assert_bitwise, run_gpu
 pytestmark = pytest.mark.gpu
 
 
-def check(rtx, oracle, tracer, mgr, frames=2, first=0, kernels=(0, 1, 2), what=""):
+def check(rtx, oracle, tracer, mgr, frames=2, first=0, kernels=(0, 1, 2, 3), what=""):
     b = mgr.build_buffers()
     want, want_last, _ = oracle.render(*b, first, frames)
     for k in kernels:

@@ -35,7 +35,7 @@ def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=0, shade_thr
     return tracer.read_accum(), tracer.read_last_frame()
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_config1_spheres_bitwise(rtx, oracle, tracer, kernel):
     """configs[0]: 16 spheres, 256x256, 4 rays, 3 bounces — full image, frame 0."""
     b = rtx.scenes.config1().build_buffers()
@@ -54,7 +54,7 @@ def test_config1_accumulate_three_frames(rtx, oracle, tracer):
     assert want_acc.max() <= 1.0
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_mesh_scene_bvh_bitwise(rtx, oracle, tracer, mode, kernel):
     """Triangles through the BVH == the reference's flat chunk loop (mode 0) / brute force (mode 1), for both
@@ -150,7 +150,28 @@ def test_pool_kernel_knobs_do_not_change_the_image(rtx, tracer, trav_min, pool_s
     assert_bitwise(got, ref, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, accum")
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("refill_min,trav_min,node_min", [(1, 1, 1), (64, 64, 64), (16, 24, 24), (8, 48, 4)])
+def test_wave_kernel_knobs_do_not_change_the_image(rtx, tracer, refill_min, trav_min, node_min):
+    """k_wave (256 pixel slots per wave, path state in global memory, phases on compacted slot lists) == tile-per-wave
+    kernel for any refill / suspend / node-loop threshold; odd image size, three frames in one launch, and the ray count."""
+    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
+    ref, ref_last = run_gpu(tracer, b, 2, 3, kernel=0)
+    rays_ref = tracer.stats()["rays"]
+    for k, v in (("refill_min", refill_min), ("wave_trav_min", trav_min), ("wave_node_min", node_min), ("tile_lpt", 0)):
+        tracer.set_option(k, v)
+    try:
+        got, got_last = run_gpu(tracer, b, 2, 3, kernel=3)
+        rays = tracer.stats()["rays"]
+    finally:
+        for k, v in (("refill_min", 16), ("wave_trav_min", 24), ("wave_node_min", 24), ("tile_lpt", 1)):
+            tracer.set_option(k, v)
+    what = f"wave(refill={refill_min}, trav_min={trav_min}, node_min={node_min})"
+    assert_bitwise(got_last, ref_last, what + " vs tile kernel, last frame")
+    assert_bitwise(got, ref, what + " vs tile kernel, accum")
+    assert rays == rays_ref
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_interleaved_bands_are_decomposition_invariant(rtx, tracer, kernel):
     """8-row bands dealt round-robin to 3 'ranks' reassemble to the undivided image (61 rows: partial last band)."""
     b = rtx.scenes.mesh_test_scene(80, 61).build_buffers()
