@@ -384,6 +384,9 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     S.tri_geo = c->d_tri_geo.p; S.tri_nrm = c->d_tri_nrm.p; S.chunk_mat = c->d_chunk_mat.p; S.chunk_box = c->d_chunk_box.p;
     S.raw_tris = c->d_raw_tris.p; S.raw_chunk_range = c->d_raw_range.p;
     S.ns = (int)c->h_spheres.size(); S.nn = (int)c->bvh.nodes.size();
+    // the kernels address nodes and BVH-order triangles with 32-bit byte offsets (128 B and 48 B records)
+    if (c->bvh.nodes.size() >= ((size_t)1 << 25) || (c->geom_local ? c->h_local_tris.size() : c->h_tris.size()) >= ((size_t)1 << 32) / 48)
+        return fail(c, -7, "scene too large for 32-bit record offsets (%zu BVH nodes)", c->bvh.nodes.size());
     S.nt = c->geom_local ? (int)c->h_local_tris.size() : (int)c->h_tris.size();
     S.nm = c->geom_local ? (int)c->h_lchunks.size() : (int)c->h_mesh.size();
 

@@ -154,6 +154,7 @@ struct RaySlab {
     v3 inv;             // 1 / d  (RayBoundingBox :179 — also used by the literal chunk filter)
     v3 oinv;            // o * inv
     uint32_t nx, ny, nz;   // byte offsets of the near-plane float4s (x: 0|48, y: 16|64, z: 32|80)
+    uint32_t fx, fy, fz;   // ... and of the far-plane ones (the other of each pair)
 };
 
 __device__ __forceinline__ RaySlab make_slab(v3 o, v3 d)
@@ -164,6 +165,7 @@ __device__ __forceinline__ RaySlab make_slab(v3 o, v3 d)
     r.nx = d.x < 0.0f ? 48u : 0u;
     r.ny = d.y < 0.0f ? 64u : 16u;
     r.nz = d.z < 0.0f ? 80u : 32u;
+    r.fx = 48u - r.nx; r.fy = 80u - r.ny; r.fz = 112u - r.nz;
     return r;
 }
 
@@ -173,11 +175,14 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
                                           float& t0, float& t1, float& t2, float& t3,
                                           uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3)
 {
-    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)cur * 128u;
-    const float4 px = *reinterpret_cast<const float4*>(nb + r.nx), qx = *reinterpret_cast<const float4*>(nb + (48u - r.nx));
-    const float4 py = *reinterpret_cast<const float4*>(nb + r.ny), qy = *reinterpret_cast<const float4*>(nb + (80u - r.ny));
-    const float4 pz = *reinterpret_cast<const float4*>(nb + r.nz), qz = *reinterpret_cast<const float4*>(nb + (112u - r.nz));
-    const uint4 ch = *reinterpret_cast<const uint4*>(nb + 96);
+    // 32-bit byte offsets from the (wave-uniform) node array: one shift and six adds per node instead of 64-bit address
+    // arithmetic per load (the host refuses BVHs of 2^25 nodes or more)
+    const char* nb = reinterpret_cast<const char*>(nodes);
+    const uint32_t base = cur << 7;
+    const float4 px = *reinterpret_cast<const float4*>(nb + (base + r.nx)), qx = *reinterpret_cast<const float4*>(nb + (base + r.fx));
+    const float4 py = *reinterpret_cast<const float4*>(nb + (base + r.ny)), qy = *reinterpret_cast<const float4*>(nb + (base + r.fy));
+    const float4 pz = *reinterpret_cast<const float4*>(nb + (base + r.nz)), qz = *reinterpret_cast<const float4*>(nb + (base + r.fz));
+    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
     c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
     const float INF = __builtin_inff();
 #define RT_SLAB(K, TK)                                                                                                   \
@@ -198,6 +203,17 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
     RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
     if (full_sort) { RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2) }
 #undef RT_CSWAP
+}
+
+// The three float4s of BVH-order triangle `ti` (A, eAB, eAC, n) through a 32-bit byte offset from the wave-uniform array
+// (the host refuses scenes of 2^32 / 48 triangles or more).
+__device__ __forceinline__ void load_tri(const float4* __restrict__ tri_geo, uint32_t ti, float4& g0, float4& g1, float4& g2)
+{
+    const char* tb = reinterpret_cast<const char*>(tri_geo);
+    const uint32_t off = ti * 48u;
+    g0 = *reinterpret_cast<const float4*>(tb + off);
+    g1 = *reinterpret_cast<const float4*>(tb + (off + 16u));
+    g2 = *reinterpret_cast<const float4*>(tb + (off + 32u));
 }
 
 // ---- closest hit: spheres, then BVH ---------------------------------------------------------------------
@@ -247,8 +263,8 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                 const uint32_t first = (cur & 0x7FFFFFFFu) >> 2, count = (cur & 3u) + 1u;
                 for (uint32_t j = 0; j < count; ++j) {
                     const uint32_t ti = first + j;
-                    const float4* tg = S.tri_geo + (size_t)ti * 3;
-                    const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                    float4 g0, g1, g2;
+                    load_tri(S.tri_geo, ti, g0, g1, g2);
                     float dst, u, v;
                     if (COUNT) cnt.tris++;
                     phase_tick<COUNT>(cnt, 1);

@@ -196,8 +196,8 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                     // ---- TRI step
                     if (fly && (int)cur < 0) {
                         const uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
-                        const float4* tg = S.tri_geo + (size_t)ti * 3;
-                        const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                        float4 g0, g1, g2;
+                        load_tri(S.tri_geo, ti, g0, g1, g2);
                         float dst, u, v;
                         if (COUNT) cnt.tris++;
                         phase_tick<COUNT>(cnt, 1);

@@ -290,8 +290,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
                     const uint32_t last = ti + (cur & 3u);
                     for (; ti <= last; ++ti) {
-                        const float4* tg = S.tri_geo + (size_t)ti * 3;
-                        const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                        float4 g0, g1, g2;
+                        load_tri(S.tri_geo, ti, g0, g1, g2);
                         float dst, u, v;
                         if (COUNT) cnt.tris++;
                         phase_tick<COUNT>(cnt, 1);
