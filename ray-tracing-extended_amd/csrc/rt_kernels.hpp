@@ -87,6 +87,12 @@ struct TravStack {
     }
 };
 
+// wave-wide vote straight from the i1 (HIP's __ballot(int) round-trips the predicate through a VGPR: two half-rate VALU ops)
+__device__ __forceinline__ unsigned long long ballot_(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+// vote on a && b: two compares into SGPR pairs and a scalar AND (the vote of an i1 that is not itself a compare is
+// lowered through a VGPR again)
+__device__ __forceinline__ unsigned long long ballot2_(bool a, bool b) { return __builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b); }
+
 struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; };
 constexpr int kNumCounters = 15;
 
@@ -95,7 +101,7 @@ __device__ __forceinline__ void phase_tick(Counters& cnt, int k)
 {
     if (COUNT) {
         cnt.phase_lanes[k]++;
-        const unsigned long long m = __ballot(1);
+        const unsigned long long m = ballot_(1);
         if ((unsigned)(__builtin_ctzll(m)) == (threadIdx.x & 63u)) cnt.phase_execs[k]++;
     }
 }

@@ -100,13 +100,13 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
         // ================================ census ================================
         __builtin_amdgcn_wave_barrier();
         const uint32_t st0 = SLOT(SB, lane) & 15u, st1 = SLOT(SB, lane + 64) & 15u;
-        const unsigned long long hit0 = __ballot(st0 == HIT), hit1 = __ballot(st1 == HIT);
-        const unsigned long long pen0 = __ballot(st0 == PEND), pen1 = __ballot(st1 == PEND);
+        const unsigned long long hit0 = ballot_(st0 == HIT), hit1 = ballot_(st1 == HIT);
+        const unsigned long long pen0 = ballot_(st0 == PEND), pen1 = ballot_(st1 == PEND);
         const bool f0 = st0 == PATHEND || st0 == MISS || (st0 == EMPTY && pixels_left);
         const bool f1 = st1 == PATHEND || st1 == MISS || (st1 == EMPTY && pixels_left);
-        const unsigned long long fin0 = __ballot(f0), fin1 = __ballot(f1);
+        const unsigned long long fin0 = ballot_(f0), fin1 = ballot_(f1);
         const int nHit = __popcll(hit0) + __popcll(hit1), nPend = __popcll(pen0) + __popcll(pen1);
-        const int nFin = __popcll(fin0) + __popcll(fin1), nFly = __popcll(__ballot(fly));
+        const int nFin = __popcll(fin0) + __popcll(fin1), nFly = __popcll(ballot_(fly));
         if (nHit + nPend + nFin + nFly == 0) break;
 
         int phase;                      // 0 TRAVERSE, 1 SHADE, 2 FINISH
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
             for (unsigned int tguard = 0; tguard < (1u << 24); ++tguard) {
                 if (refill) {
                     // ---- idle lanes take pending rays
-                    const unsigned long long idle = __ballot(!fly);
+                    const unsigned long long idle = ballot_(!fly);
                     const int avail = nPend - pendNext;
                     if (avail > 0 && idle != 0) {
                         const int rank = __popcll(idle & lt_mask);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                     }
                     refill = false;
                 }
-                const unsigned long long mFly = __ballot(fly);
+                const unsigned long long mFly = ballot_(fly);
                 const int nF = __popcll(mFly);
                 if (nF == 0) { if (pendNext < nPend) { refill = true; continue; } break; }
                 if (pendNext >= nPend && nF < A.trav_min_lanes && nF < 64) {
@@ -174,9 +174,9 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                     const uint32_t s0 = SLOT(SB, lane) & 15u, s1 = SLOT(SB, lane + 64) & 15u;
                     const bool other = (s0 == HIT || s0 == MISS || s0 == PATHEND || (s0 == EMPTY && pixels_left))
                                     || (s1 == HIT || s1 == MISS || s1 == PATHEND || (s1 == EMPTY && pixels_left));
-                    if (__ballot(other) != 0) break;
+                    if (ballot_(other) != 0) break;
                 }
-                const int nNode = __popcll(__ballot(fly && (int)cur >= 0));
+                const int nNode = __popcll(ballot_(fly && (int)cur >= 0));
                 if (2 * nNode >= nF) {
                     // ---- NODE step
                     if (fly && (int)cur >= 0) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                     SLOT(SB, myslot) = (SLOT(SB, myslot) & ~15u) | (best.id == kNone ? MISS : HIT);
                     fly = false;
                 }
-                if (__ballot(!fly) != 0 && pendNext < nPend) refill = true;
+                if (ballot_(!fly) != 0 && pendNext < nPend) refill = true;
             }
             // ---- suspend what is still in flight: the best hit so far goes back to the slot
             if (fly) { SLOTF(HT, myslot) = best.t; SLOT(HID, myslot) = best.id; SLOTF(HU, myslot) = best.u; SLOTF(HV, myslot) = best.v; }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
             bool have_pixel = mine && st != EMPTY;
             if (have_pixel) { ly = (int)(pix / W); px = (int)(pix - (uint32_t)ly * W); }
             for (unsigned int rguard = 0; rguard < (1u << 24); ++rguard) {
-                const unsigned long long need = __ballot(mine && st == EMPTY);
+                const unsigned long long need = ballot_(mine && st == EMPTY);
                 if (need == 0) break;
                 if (!pixels_left) { if (mine && st == EMPTY) st = DEAD; break; }
                 unsigned int base = 0;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     };
 
     for (;;) {
-        const int nTrav = __popcll(__ballot(mode == kModeTrav)), nShade = __popcll(__ballot(mode == kModeShade));
+        const int nTrav = __popcll(ballot_(mode == kModeTrav)), nShade = __popcll(ballot_(mode == kModeShade));
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
                 // ---- pixel refill: tile-major global order; indices outside the strip are skipped
                 while (!A.tile_sync) {
-                    const unsigned long long need = __ballot(px < 0 && mode != kModeDead);
+                    const unsigned long long need = ballot_(px < 0 && mode != kModeDead);
                     if (need == 0) break;
                     if (px < 0 && mode != kModeDead) {
                         unsigned int base = 0;
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
             for (;;) {
                 for (;;) {
-                    const int nAtNode = __popcll(__ballot(mode == kModeTrav && (int)cur >= 0));
+                    const int nAtNode = __popcll(ballot2_(mode == kModeTrav, (int)cur >= 0));
                     if (nAtNode == 0) break;
-                    if (nAtNode < A.node_min && __ballot(mode == kModeTrav && (int)cur < 0) != 0) break;   // few descenders: serve the leaves first
+                    if (nAtNode < A.node_min && ballot2_(mode == kModeTrav, (int)cur < 0) != 0) break;   // few descenders: serve the leaves first
                     if (mode == kModeTrav && (int)cur >= 0) {
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     if (sp > 0) { --sp; cur = stk[sp * 64]; }
                     else { cur = kNone; mode = kModeShade; }
                 }
-                if (__ballot(mode == kModeTrav) == 0) break;
-                if (__popcll(__ballot(mode == kModeShade)) >= A.shade_threshold) break;
+                if (ballot_(mode == kModeTrav) == 0) break;
+                if (__popcll(ballot_(mode == kModeShade)) >= A.shade_threshold) break;
             }
         }
     }

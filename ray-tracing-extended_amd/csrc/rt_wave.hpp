@@ -99,12 +99,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
         for (int k = 0; k < P / 64; ++k) {
             const uint32_t st = sst[lane + 64 * k];
-            hitm[k] = __ballot(st == HIT);
-            penm[k] = __ballot(st == PEND);
-            finm[k] = __ballot(st == PATHEND || st == MISS || (st == EMPTY && pixels_left));
+            hitm[k] = ballot_(st == HIT);
+            penm[k] = ballot_(st == PEND);
+            finm[k] = ballot_(st == PATHEND || st == MISS || (st == EMPTY && pixels_left));
             nHit += __popcll(hitm[k]); nPend += __popcll(penm[k]); nFin += __popcll(finm[k]);
         }
-        const int nFly = __popcll(__ballot(fly));
+        const int nFly = __popcll(ballot_(fly));
         if (nHit + nPend + nFin + nFly == 0) break;
 
         // the phase that fills the most lanes; TRAVERSE only when it can make progress (it leaves again as soon as the
@@ -139,11 +139,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
             RaySlab slab = make_slab(o, d);
             for (unsigned int tguard = 0; tguard < (1u << 24); ++tguard) {
-                int nF = __popcll(__ballot(fly));
+                int nF = __popcll(ballot_(fly));
                 const int avail = nPend - pendNext;
                 if (avail > 0 && 64 - nF >= min(A.refill_min, avail)) {
                     // ---- the idle lanes take pending rays together
-                    const unsigned long long idle = __ballot(!fly);
+                    const unsigned long long idle = ballot_(!fly);
                     const int rank = __popcll(idle & lt_mask);
                     if (!fly && rank < avail) {
                         myslot = list[pendNext + rank];
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
                 // ---- one while-while round: node steps, then whole leaves
                 for (unsigned int nguard = 0; nguard < (1u << 20); ++nguard) {
-                    const int nAtNode = __popcll(__ballot(fly && (int)cur >= 0));
+                    const int nAtNode = __popcll(ballot2_(fly, (int)cur >= 0));
                     if (nAtNode == 0) break;
-                    if (nAtNode < A.node_min && __ballot(fly && (int)cur < 0 && cur != kNone) != 0) break;   // few descenders: serve the leaves first
+                    if (nAtNode < A.node_min && ballot_(fly && (int)cur < 0 && cur != kNone) != 0) break;   // few descenders: serve the leaves first
                     if (fly && (int)cur >= 0) {
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     sst[myslot] = (unsigned char)(best.id == kNone ? MISS : HIT);
                     fly = false;
                 }
-                other += __popcll(__ballot(done));
-                nF = __popcll(__ballot(fly));
+                other += __popcll(ballot_(done));
+                nF = __popcll(ballot_(fly));
                 if (pendNext >= nPend) {
                     if (nF == 0) break;
                     if (nF < A.trav_min_lanes && other > 0) break;      // the stragglers stay suspended on their lanes
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             // ---- pixel refill from the work queue: item = (frame, tile) in costliest-first order, pixel by pixel
             bool have_pixel = mine && st != EMPTY;
             for (unsigned int rguard = 0; rguard < (1u << 24); ++rguard) {
-                const unsigned long long need = __ballot(mine && st == EMPTY);
+                const unsigned long long need = ballot_(mine && st == EMPTY);
                 if (need == 0) break;
                 if (!pixels_left) { if (mine && st == EMPTY) st = DEAD; break; }
                 unsigned int base = 0;
