@@ -182,3 +182,38 @@ def test_4k_frame_vs_oracle_brute_mode(rtx, oracle, tracer):
     m = rtx.scenes.config4()
     m.numRaysPerPixel = 1
     _full_frame_vs_oracle(oracle, tracer, m, "config4 4K vs oracle", mode=1)
+
+
+def test_render_scene_tool_writes_what_the_tracer_holds(rtx, tracer, tmp_path):
+    """tools/render_scene.py (scene file -> OnRenderImage -> PNG / EXR): the EXR equals the accumulated resultTexture of the
+    same render through the API, bit for bit; the PNG decodes to the display step's bytes."""
+    import struct
+    import subprocess
+    import sys
+    import zlib
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    scene = os.path.join(GOLDEN, "scenes", "Reflective_Balls.npz")
+    png, exr = str(tmp_path / "o.png"), str(tmp_path / "o.exr")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "render_scene.py"), scene, "--width", "160", "--height", "90",
+                          "--frames", "3", "--rays", "4", "--png", png, "--exr", exr], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "rays in" in out.stdout
+    from rtx_amd import unity_scene
+    m = unity_scene.load_scene_npz(scene, 160, 90, backend=tracer)
+    m.numRaysPerPixel = 4
+    tracer.set_option("kernel", -1)
+    want = m.OnRenderImage(frames=3)
+    got = rtx.imageio.read_exr(exr)
+    assert_bitwise(got, want, "render_scene.py EXR vs API")
+    disp = tracer.read_display()
+    raw = open(png, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        if tag == b"IDAT":
+            idat += raw[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(90, 1 + 160 * 3)
+    assert (rows[:, 0] == 0).all()
+    assert (rows[:, 1:].reshape(90, 160, 3) == disp[::-1, :, :3]).all()
