@@ -11,6 +11,9 @@
 namespace rtbvh {
 namespace {
 
+int g_bins = 32;            // SAH bins per axis (set_tuning)
+float g_cost_exp = 1.0f;    // the SAH's subtree-cost model: area * count^g_cost_exp
+
 struct Box {
     float mn[3], mx[3];
     void reset()
@@ -64,12 +67,13 @@ struct Builder {
             bn[me].first = first; bn[me].count = count;
             return me;
         }
-        constexpr int NB = 32;
+        constexpr int NBMAX = 128;
+        const int NB = g_bins;
         int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
         for (int a = 0; a < 3; ++a) {
             float lo = cb.mn[a], ext = cb.mx[a] - cb.mn[a];
             if (!(ext > 0.f)) continue;
-            Box bb[NB]; uint32_t bc[NB];
+            Box bb[NBMAX]; uint32_t bc[NBMAX];
             for (int k = 0; k < NB; ++k) { bb[k].reset(); bc[k] = 0; }
             float scale = (float)NB / ext;
             for (uint32_t i = first; i < first + count; ++i) {
@@ -78,15 +82,52 @@ struct Builder {
                 k = std::min(std::max(k, 0), NB - 1);
                 bb[k].grow(tbox[t]); bc[k]++;
             }
-            float la[NB]; uint32_t lc[NB];
+            float la[NBMAX]; uint32_t lc[NBMAX];
             Box acc; acc.reset(); uint32_t c = 0;
             for (int k = 0; k < NB - 1; ++k) { acc.grow(bb[k]); c += bc[k]; la[k] = acc.half_area(); lc[k] = c; }
             acc.reset(); c = 0;
             for (int k = NB - 1; k > 0; --k) {
                 acc.grow(bb[k]); c += bc[k];
                 if (lc[k - 1] == 0 || c == 0) continue;
-                float cost = la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)c;
+                float cost = g_cost_exp == 1.0f ? la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)c
+                                                : la[k - 1] * std::pow((float)lc[k - 1], g_cost_exp) + acc.half_area() * std::pow((float)c, g_cost_exp);
                 if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+            }
+        }
+        // Large-triangle isolation: centroid binning can never separate a triangle whose box spans the node (a floor quad
+        // under 100k small triangles) from the rest, so it would sink to the bottom of the tree and inflate every box on
+        // its way.  Candidate split: the one or two largest triangles of the node against everything else.
+        {
+            uint32_t big[2] = { 0, 0 }; float bigA[2] = { -1.f, -1.f };
+            for (uint32_t i = first; i < first + count; ++i) {
+                const float ar = tbox[idx[i]].half_area();
+                if (ar > bigA[0]) { bigA[1] = bigA[0]; big[1] = big[0]; bigA[0] = ar; big[0] = i; }
+                else if (ar > bigA[1]) { bigA[1] = ar; big[1] = i; }
+            }
+            const float nodeA = b.half_area();
+            if (bigA[0] > 0.25f * nodeA && count > 2) {
+                for (int k = 1; k <= 2; ++k) {
+                    if (k == 2 && !(bigA[1] > 0.25f * nodeA && count > 3)) break;
+                    Box in; in.reset(); Box rest; rest.reset();
+                    for (uint32_t i = first; i < first + count; ++i) {
+                        const bool isBig = i == big[0] || (k == 2 && i == big[1]);
+                        (isBig ? in : rest).grow(tbox[idx[i]]);
+                    }
+                    const float ce = g_cost_exp;
+                    const float cost = in.half_area() * std::pow((float)k, ce) + rest.half_area() * std::pow((float)(count - k), ce);
+                    if (cost < best_cost) { best_cost = cost; best_axis = 3 + k; }
+                }
+                if (best_axis >= 4) {
+                    const int k = best_axis - 3;
+                    // move the k big triangles to the front of the range (order inside a range is free)
+                    uint32_t a0 = big[0], a1 = big[1];
+                    std::swap(idx[first], idx[a0]);
+                    if (k == 2) { if (a1 == first) a1 = a0; std::swap(idx[first + 1], idx[a1]); }
+                    int l = build_range(first, (uint32_t)k, level + 1);
+                    int r = build_range(first + k, count - k, level + 1);
+                    bn[me].left = l; bn[me].right = r;
+                    return me;
+                }
             }
         }
         uint32_t mid;
@@ -125,6 +166,12 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 }
 
 } // namespace
+
+void set_tuning(int bins, int cost_exp_percent)
+{
+    g_bins = std::min(std::max(bins, 2), 128);
+    g_cost_exp = (float)std::min(std::max(cost_exp_percent, 10), 300) / 100.0f;
+}
 
 void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out)
 {

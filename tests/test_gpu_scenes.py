@@ -202,6 +202,7 @@ def test_render_scene_tool_writes_what_the_tracer_holds(rtx, tracer, tmp_path):
     m = unity_scene.load_scene_npz(scene, 160, 90, backend=tracer)
     m.numRaysPerPixel = 4
     tracer.set_option("kernel", -1)
+    tracer.set_rows(0, 90)
     want = m.OnRenderImage(frames=3)
     got = rtx.imageio.read_exr(exr)
     assert_bitwise(got, want, "render_scene.py EXR vs API")
