@@ -99,6 +99,7 @@ struct rt_ctx {
     int opt_tile_w_log2 = 3;        // k_trace: tile width 2^n (n = 3: 8x8 tiles)
     int opt_bvh_bins = 32, opt_bvh_cost_exp = 100;   // BVH builder: SAH bins per axis; exponent (percent) of the count in the SAH cost model
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
+    int opt_stream_stack = 37;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
     int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
@@ -414,6 +415,9 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream || waved ? 3 : 0);    // the branch-free push writes up to 3 slots past the top
     const bool tile_kernel = !stream && !pooled && !waved && var != Variant::Flat;   // k_trace, PCG or Philox
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
+    // k_stream: at most opt_stream_stack entries per lane in LDS (37 = four workgroups per CU); a deeper worst case spills
+    const bool stream_spill = stream && F.stack_cap > c->opt_stream_stack;
+    if (stream_spill) F.stack_cap = c->opt_stream_stack;
     F.full_sort = c->opt_full_sort;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
     F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
@@ -461,6 +465,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         WA.refill_min = std::max(1, std::min(64, c->opt_refill_min));
         WA.trav_min_lanes = std::max(1, std::min(64, c->opt_wave_trav_min));
         WA.node_min = std::max(1, std::min(64, c->opt_wave_node_min));
+    }
+    if (stream_spill) {
+        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack + 3 - F.stack_cap) * PA.gstack_stride));
+        F.gstack = c->d_gstack.p; F.gstack_stride = PA.gstack_stride;
     }
     if (tile_kernel && c->bvh.maxStack > F.stack_cap) {
         RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - F.stack_cap) * PA.gstack_stride));
@@ -823,6 +831,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "wave_trav_min")) { if (value < 1 || value > 64) return fail(c, -2, "wave_trav_min must be in [1,64]"); c->opt_wave_trav_min = value; }
     else if (!std::strcmp(name, "trav_min_lanes")) { if (value < 1 || value > 64) return fail(c, -2, "trav_min_lanes must be in [1,64]"); c->opt_trav_min_lanes = value; }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
+    else if (!std::strcmp(name, "stream_stack")) { if (value < 4 || value > 128) return fail(c, -2, "stream_stack must be in [4,128]"); c->opt_stream_stack = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }
     else if (!std::strcmp(name, "bvh_bins")) { if (value < 2 || value > 128) return fail(c, -2, "bvh_bins must be in [2,128]"); if (value != c->opt_bvh_bins) c->scene_dirty = true; c->opt_bvh_bins = value; }
     else if (!std::strcmp(name, "bvh_cost_exp")) { if (value < 10 || value > 300) return fail(c, -2, "bvh_cost_exp must be in [10,300] (percent)"); if (value != c->opt_bvh_cost_exp) c->scene_dirty = true; c->opt_bvh_cost_exp = value; }

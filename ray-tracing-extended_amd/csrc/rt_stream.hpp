@@ -40,6 +40,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
+    // The LDS stack holds F.stack_cap entries per lane; when the BVH's worst case is deeper (F.gstack != null) the entries
+    // past it spill to global memory ([entry - cap][lane of the launch]) — rare, but it keeps four workgroups per CU
+    // resident whatever the tree depth.
+    const int cap = F.stack_cap;
+    uint32_t* const gstk = F.gstack ? F.gstack + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
     Counters cnt = {};
     const rt_params& p = F.p;
     const float* M = p.camLocalToWorld;
@@ -277,12 +282,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
                         node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
-                        // branch-free push of the three farther children (far -> near); slots past the new top are garbage
-                        stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
-                        stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
-                        stk[sp * 64] = c1; sp += (t1 < INF) ? 1 : 0;
+                        if (gstk == nullptr || ballot_(sp + 3 > cap) == 0) {
+                            // branch-free push of the three farther children (far -> near); slots past the new top are garbage
+                            stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
+                            stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
+                            stk[sp * 64] = c1; sp += (t1 < INF) ? 1 : 0;
+                        } else {
+                            // some lane is within three entries of the LDS part: checked pushes, spilling past it
+                            if (t3 < INF) { if (sp < cap) stk[sp * 64] = c3; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c3; ++sp; }
+                            if (t2 < INF) { if (sp < cap) stk[sp * 64] = c2; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c2; ++sp; }
+                            if (t1 < INF) { if (sp < cap) stk[sp * 64] = c1; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c1; ++sp; }
+                        }
                         if (t0 < INF) cur = c0;
-                        else if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                        else if (sp > 0) { --sp; cur = (sp < cap) ? stk[sp * 64] : gstk[(size_t)(sp - cap) * F.gstack_stride]; }
                         else { cur = kNone; mode = kModeShade; }
                     }
                 }
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                         }
                     }
-                    if (sp > 0) { --sp; cur = stk[sp * 64]; }
+                    if (sp > 0) { --sp; cur = (sp < cap) ? stk[sp * 64] : gstk[(size_t)(sp - cap) * F.gstack_stride]; }
                     else { cur = kNone; mode = kModeShade; }
                 }
                 if (ballot_(mode == kModeTrav) == 0) break;

@@ -150,6 +150,25 @@ def test_pool_kernel_knobs_do_not_change_the_image(rtx, tracer, trav_min, pool_s
     assert_bitwise(got, ref, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, accum")
 
 
+@pytest.mark.parametrize("stream_stack", [4, 7, 12])
+def test_stream_stack_spill_does_not_change_the_image(rtx, tracer, stream_stack):
+    """k_stream with only a few traversal-stack entries per lane in LDS (the rest spills to global memory) == tile kernel:
+    image and ray count; the mesh scene's BVH needs more entries than any of the three caps."""
+    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
+    ref, ref_last = run_gpu(tracer, b, 2, 2, kernel=0)
+    rays_ref = tracer.stats()["rays"]
+    assert tracer.stats()["bvhMaxStack"] + 3 > 12
+    tracer.set_option("stream_stack", stream_stack)
+    try:
+        got, got_last = run_gpu(tracer, b, 2, 2, kernel=1)
+        rays = tracer.stats()["rays"]
+    finally:
+        tracer.set_option("stream_stack", 37)
+    assert_bitwise(got_last, ref_last, f"stream(stack={stream_stack}) vs tile kernel, last frame")
+    assert_bitwise(got, ref, f"stream(stack={stream_stack}) vs tile kernel, accum")
+    assert rays == rays_ref
+
+
 @pytest.mark.parametrize("refill_min,trav_min,node_min", [(1, 1, 1), (64, 64, 64), (16, 24, 24), (8, 48, 4)])
 def test_wave_kernel_knobs_do_not_change_the_image(rtx, tracer, refill_min, trav_min, node_min):
     """k_wave (256 pixel slots per wave, path state in global memory, phases on compacted slot lists) == tile-per-wave
