@@ -13,6 +13,7 @@ namespace {
 
 int g_bins = 32;            // SAH bins per axis (set_tuning)
 float g_cost_exp = 1.0f;    // the SAH's subtree-cost model: area * count^g_cost_exp
+int g_reinsert_passes = 0;  // insertion-based optimisation passes after the top-down build
 
 struct Box {
     float mn[3], mx[3];
@@ -151,6 +152,83 @@ struct Builder {
     }
 };
 
+// Insertion-based optimisation of the binary tree (after Bittner, Hapala, Havran, "Fast insertion-based optimization of
+// bounding volume hierarchies", CGF 2013): every subtree in turn is cut out (its parent node goes with it, the sibling
+// moves up) and put back where it adds the least surface area to the tree — found by a branch-and-bound search over
+// (area the ancestors grow by) + (area of the new common parent).  Only links and boxes change; leaves keep their triangle
+// ranges, so the traversal still returns the same closest hit.
+struct Reinserter {
+    std::vector<BNode>& bn;
+    std::vector<int32_t> parent;
+    int root;
+    struct Cand { float induced; int node; bool operator<(const Cand& o) const { return induced > o.induced; } };
+    std::vector<Cand> heap;
+
+    Reinserter(std::vector<BNode>& nodes, int r) : bn(nodes), parent(nodes.size(), -1), root(r)
+    {
+        for (int i = 0; i < (int)bn.size(); ++i)
+            if (bn[i].count == 0) { parent[bn[i].left] = i; parent[bn[i].right] = i; }
+    }
+    double cost() const            // sum of the internal nodes' areas (the part of the SAH the topology decides)
+    {
+        double c = 0;
+        for (const BNode& n : bn) if (n.count == 0) c += n.box.half_area();
+        return c;
+    }
+    void refit_up(int i)
+    {
+        while (i >= 0) {
+            Box b = bn[bn[i].left].box; b.grow(bn[bn[i].right].box);
+            if (std::memcmp(&b, &bn[i].box, sizeof b) == 0) break;
+            bn[i].box = b;
+            i = parent[i];
+        }
+    }
+    void reinsert(int x)
+    {
+        const int p = parent[x];
+        if (p < 0) return;
+        const int g = parent[p];
+        if (g < 0) return;                                   // children of the root stay
+        const int s = bn[p].left == x ? bn[p].right : bn[p].left;
+        (bn[g].left == p ? bn[g].left : bn[g].right) = s;    // the sibling takes the parent's place
+        parent[s] = g;
+        refit_up(g);
+        const Box bx = bn[x].box;
+        const float ax = bx.half_area();
+        float bestCost = std::numeric_limits<float>::infinity(); int best = s;
+        heap.clear();
+        heap.push_back({ 0.f, root });
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end());
+            const Cand c = heap.back(); heap.pop_back();
+            if (c.induced + ax >= bestCost) break;           // nothing below can beat the best position
+            Box m = bn[c.node].box; m.grow(bx);
+            const float total = c.induced + m.half_area();
+            if (total < bestCost) { bestCost = total; best = c.node; }
+            const float below = total - bn[c.node].box.half_area();
+            if (bn[c.node].count == 0 && below + ax < bestCost) {
+                heap.push_back({ below, bn[c.node].left });  std::push_heap(heap.begin(), heap.end());
+                heap.push_back({ below, bn[c.node].right }); std::push_heap(heap.begin(), heap.end());
+            }
+        }
+        const int y = best, py = parent[y];
+        bn[p].left = y; bn[p].right = x; bn[p].count = 0;
+        parent[y] = p; parent[x] = p; parent[p] = py;
+        if (py >= 0) (bn[py].left == y ? bn[py].left : bn[py].right) = p; else root = p;
+        Box b = bn[y].box; b.grow(bx); bn[p].box = b;
+        refit_up(py);
+    }
+    void pass()
+    {
+        std::vector<int> order;
+        order.reserve(bn.size());
+        for (int i = 0; i < (int)bn.size(); ++i) if (parent[i] >= 0 && parent[parent[i]] >= 0) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bn[a].box.half_area() > bn[b].box.half_area(); });
+        for (int x : order) reinsert(x);
+    }
+};
+
 // Widen a child box so the slab test stays conservative under float rounding.  The kernels evaluate
 // t = plane*inv - (o*inv) with one FMA: the absolute error is about (2|o| + |plane|) * 2^-24 in space, where the ray
 // origin o is the camera or a surface point.  G bounds both (scene coordinates and camera position), so a floor of
@@ -167,8 +245,9 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 
 } // namespace
 
-void set_tuning(int bins, int cost_exp_percent)
+void set_tuning(int bins, int cost_exp_percent, int reinsert_passes)
 {
+    g_reinsert_passes = std::min(std::max(reinsert_passes, 0), 16);
     g_bins = std::min(std::max(bins, 2), 128);
     g_cost_exp = (float)std::min(std::max(cost_exp_percent, 10), 300) / 100.0f;
 }
@@ -194,6 +273,22 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
     }
     B.bn.reserve(2 * (size_t)n_tris / 2 + 16);
     int root = B.build_range(0, n_tris, 0);
+    if (g_reinsert_passes > 0 && B.bn.size() > 7) {
+        Reinserter R(B.bn, root);
+        for (int it = 0; it < g_reinsert_passes; ++it) {
+            const double before = R.cost();
+            R.pass();
+            if (!(R.cost() < 0.995 * before)) break;
+        }
+        root = R.root;
+        // depth of the rewired tree
+        std::vector<std::pair<int, int>> st; st.push_back({ root, 0 }); B.depth = 0;
+        while (!st.empty()) {
+            auto [n, d] = st.back(); st.pop_back();
+            B.depth = std::max(B.depth, d);
+            if (B.bn[n].count == 0) { st.push_back({ B.bn[n].left, d + 1 }); st.push_back({ B.bn[n].right, d + 1 }); }
+        }
+    }
     out.order = B.idx;
     out.magnitude = G;
     out.depth = B.depth;

@@ -40,8 +40,8 @@ struct Bvh {
 // the geometry can have (the camera): it widens the absolute part of the box padding.
 // max_leaf: triangles per leaf (1..kMaxLeaf).
 // Builder tuning (process-wide): SAH bins per axis (2..128, default 32) and the exponent, in percent, of the triangle count in
-// the SAH's subtree-cost model area * count^e (default 100).  The hierarchy changes, the closest hit it returns does not.
-void set_tuning(int bins, int cost_exp_percent);
+// the SAH's subtree-cost model area * count^e (default 100); passes of insertion-based optimisation of the binary tree.  The hierarchy changes, the closest hit it returns does not.
+void set_tuning(int bins, int cost_exp_percent, int reinsert_passes);
 void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out);
 
 } // namespace rtbvh

@@ -97,6 +97,7 @@ struct rt_ctx {
     int opt_tile_lpt = 1;           // k_trace: dispatch the costliest tiles first, using the costs measured by the previous launch
     int opt_frame_batch = 0;        // k_trace: frames per launch in rt_render (0 = auto, 1 = one launch per frame)
     int opt_tile_w_log2 = 3;        // k_trace: tile width 2^n (n = 3: 8x8 tiles)
+    int opt_bvh_reinsert = 0;       // BVH builder: insertion-based optimisation passes
     int opt_bvh_bins = 32, opt_bvh_cost_exp = 100;   // BVH builder: SAH bins per axis; exponent (percent) of the count in the SAH cost model
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
     int opt_stream_stack = 37;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory
@@ -168,7 +169,7 @@ int build_scene(rt_ctx* c)
     for (size_t t = 0; t < nt; ++t) if (chunk_of[t] != 0xFFFFFFFFu) live.push_back((uint32_t)t);
     std::vector<float> pos(9 * live.size());
     for (size_t i = 0; i < live.size(); ++i) std::memcpy(&pos[9 * i], c->h_tris[live[i]].posA, 36);
-    rtbvh::set_tuning(c->opt_bvh_bins, c->opt_bvh_cost_exp);
+    rtbvh::set_tuning(c->opt_bvh_bins, c->opt_bvh_cost_exp, c->opt_bvh_reinsert);
     rtbvh::build(pos.data(), 9, (uint32_t)live.size(), camera_magnitude(c->params), c->opt_max_leaf, c->bvh);
 
     const size_t nl = live.size();
@@ -323,7 +324,7 @@ int build_scene_local(rt_ctx* c)
     { int r = run_geometry_kernels(c, false); if (r) return r; }
     std::vector<rt_triangle> world(nt);
     if (nt) RT_HIP(c, hipMemcpy(world.data(), c->d_raw_tris.p, nt * sizeof(rt_triangle), hipMemcpyDeviceToHost));
-    rtbvh::set_tuning(c->opt_bvh_bins, c->opt_bvh_cost_exp);
+    rtbvh::set_tuning(c->opt_bvh_bins, c->opt_bvh_cost_exp, c->opt_bvh_reinsert);
     rtbvh::build(nt ? world[0].posA : nullptr, 18, (uint32_t)nt, local_scene_magnitude(c), c->opt_max_leaf, c->bvh);
     RT_HIP(c, c->d_nodes.ensure(c->bvh.nodes.size() * 8)); RT_HIP(c, c->d_order.ensure(nt));
     if (!c->bvh.nodes.empty()) {
@@ -834,6 +835,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "stream_stack")) { if (value < 4 || value > 128) return fail(c, -2, "stream_stack must be in [4,128]"); c->opt_stream_stack = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }
     else if (!std::strcmp(name, "bvh_bins")) { if (value < 2 || value > 128) return fail(c, -2, "bvh_bins must be in [2,128]"); if (value != c->opt_bvh_bins) c->scene_dirty = true; c->opt_bvh_bins = value; }
+    else if (!std::strcmp(name, "bvh_reinsert")) { if (value < 0 || value > 16) return fail(c, -2, "bvh_reinsert must be in [0,16]"); if (value != c->opt_bvh_reinsert) c->scene_dirty = true; c->opt_bvh_reinsert = value; }
     else if (!std::strcmp(name, "bvh_cost_exp")) { if (value < 10 || value > 300) return fail(c, -2, "bvh_cost_exp must be in [10,300] (percent)"); if (value != c->opt_bvh_cost_exp) c->scene_dirty = true; c->opt_bvh_cost_exp = value; }
     else if (!std::strcmp(name, "max_leaf")) { if (value < 1 || value > rtbvh::kMaxLeaf) return fail(c, -2, "max_leaf must be in [1,4]"); if (value != c->opt_max_leaf) c->scene_dirty = true; c->opt_max_leaf = value; }
     else if (!std::strcmp(name, "tile_w_log2")) { if (value < 0 || value > 6) return fail(c, -2, "tile_w_log2 must be in [0,6]"); c->opt_tile_w_log2 = value; }
