@@ -32,7 +32,12 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 out["pmc_per_launch_mean"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
 out["pmc_launches"] = {k: len(v) for k, v in counters.items()}
-c = out["pmc_per_launch_mean"]
+# the bench's launches differ in size (calibration frames, then multi-frame launches): "full" = the launches whose value is at
+# least half the largest one, i.e. the multi-frame launches of the warm-up and of the timed region
+full = {k: [x for x in v if x >= 0.5 * max(v)] for k, v in counters.items() if v}
+out["pmc_per_full_launch_mean"] = {k: sum(v) / len(v) for k, v in sorted(full.items())}
+out["pmc_full_launches"] = {k: len(v) for k, v in full.items()}
+c = out["pmc_per_full_launch_mean"]
 d = {}
 if "FETCH_SIZE" in c:
     d["hbm_read_bytes_raw"] = c["FETCH_SIZE"] * 1024
@@ -47,6 +52,15 @@ if "SQ_WAVE_CYCLES" in c:
             d[k + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
 if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
     d["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_ACTIVE_INST_VALU"] * 64, 1)
+if "GRBM_GUI_ACTIVE" in c:
+    # SQ_* / TA_* sums are per shader engine (32 per chip on MI355X), GRBM_GUI_ACTIVE is summed over the 8 XCDs: /32 gives the
+    # per-SIMD (resp. per-TA) busy fraction of the launch, as in profiles/hbm_traffic.json
+    if "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_active_frac_per_simd"] = c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] * 32)
+    if "TA_TA_BUSY_sum" in c:
+        d["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] * 32)
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    d["hbm_bytes_per_full_launch"] = c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024
 out["derived"] = d
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
