@@ -7,6 +7,7 @@
 // returns the same bits.  Boxes are padded (see pad_box) so that float rounding in the slab test can never
 // reject a triangle the reference arithmetic accepts.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 

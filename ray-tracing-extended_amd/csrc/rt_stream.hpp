@@ -259,7 +259,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
                         }
                         live = true;
-                        if (S.nn > 0) {
+                        // A ray with a NaN in it, or a zero direction, can hit nothing (every RaySphere / RayTriangle comparison
+                        // is false), but its slab tests are all NaN too and would "enter" every child, empty slots included:
+                        // such a query is complete as it stands.
+                        const bool traceable = o.x == o.x && o.y == o.y && o.z == o.z && a == a
+                                               && !(d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
+                        if (S.nn > 0 && traceable) {
                             slab = make_slab(o, d);                                     // RayBoundingBox :179
                             cur = 0; sp = 0; mode = kModeTrav;
                         }
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 if (mode == kModeTrav && (int)cur < 0) {            // a leaf = kLeafBit | first << 2 | count-1
                     uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
                     const uint32_t last = ti + (cur & 3u);
+                    if (cur != kNone)           // (an empty child slot can never be entered by a traceable ray; never decode one)
                     for (; ti <= last; ++ti) {
                         float4 g0, g1, g2;
                         load_tri(S.tri_geo, ti, g0, g1, g2);

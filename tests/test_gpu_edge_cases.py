@@ -140,3 +140,20 @@ def test_error_codes_not_exceptions_across_the_abi(rtx, tracer):
     tracer.upload(meshinfo=infos)                       # leave the shared context usable
     tracer.set_params(params)
     tracer.render(0, 1)
+
+
+def test_zero_normals_make_nan_rays_that_hit_nothing(rtx, oracle, tracer):
+    """A zero vertex normal makes normalize() return NaN (RayTracing.shader:293): the bounce ray is all NaN, can hit nothing,
+    and ends in the environment (whose saturate() turns NaN into 0).  Its slab tests are NaN on every axis, so a BVH must not let it "enter" the empty
+    child slots of small meshes (found by tests/test_gpu_fuzz.py: k_stream decoded an empty slot as a leaf)."""
+    m = rtx.scenes.mesh_test_scene(64, 40)
+    m.maxBounceCount, m.numRaysPerPixel = 5, 2
+    b = list(m.build_buffers())
+    tris = b[2].copy()
+    tris["normalA"][::2] = 0; tris["normalB"][::2] = 0; tris["normalC"][::2] = 0
+    b[2] = tris
+    want, want_last, _ = oracle.render(*b, 1, 2)
+    for k in (0, 1, 2, 3):
+        acc, last = run_gpu(tracer, tuple(b), 1, 2, kernel=k)
+        assert_bitwise(last, want_last, f"NaN rays, kernel {k}, last frame")
+        assert_bitwise(acc, want, f"NaN rays, kernel {k}, accum")
