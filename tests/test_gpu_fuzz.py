@@ -20,10 +20,17 @@ def _unit(v):
 
 def random_scene(rtx, seed):
     rng = np.random.default_rng(1000 + seed)
-    p, _, _, _ = rtx.scenes.mesh_test_scene(64, 48).build_buffers()
+    w, h = (64, 48) if seed % 5 else (int(rng.integers(1, 90)), int(rng.integers(1, 70)))      # every fifth: odd sizes
+    p, _, _, _ = rtx.scenes.mesh_test_scene(w, h).build_buffers()
     p = p.copy()
-    p["maxBounceCount"] = int(rng.integers(0, 7))
+    p["maxBounceCount"] = int(rng.integers(0, 7)) if seed % 7 else int(rng.integers(7, 14))
     p["numRaysPerPixel"] = int(rng.integers(1, 5))
+    far = seed % 11 == 10                         # every eleventh: the whole scene 1e5 units away from the origin
+    shift = np.float32([1e5, -2e5, 5e4]) if far else np.float32([0, 0, 0])
+    if far:
+        for k, a in enumerate((3, 7, 11)):
+            p["camLocalToWorld"][a] += shift[k]
+        p["worldSpaceCameraPos"] = p["worldSpaceCameraPos"] + shift
     p["defocusStrength"] = float(rng.choice([0.0, 0.0, 30.0, 200.0]))
     p["divergeStrength"] = float(rng.choice([0.0, 0.3, 2.0]))
     p["environmentEnabled"] = int(rng.integers(0, 2))
@@ -60,7 +67,7 @@ def random_scene(rtx, seed):
             pos[1, 2] = pos[1, 1] = pos[1, 0]     # a point
             if seed % 4 == 0:
                 pos[2, 2, 0] = np.nan
-        chunks.append((pos.astype(np.float32), rng.choice(["tight", "tight", "tight", "loose", "cut"])))
+        chunks.append(((pos + shift).astype(np.float32), rng.choice(["tight", "tight", "tight", "loose", "cut"])))
     n = sum(len(c[0]) for c in chunks)
     tris = np.zeros(n, rtx.TRIANGLE)
     infos = np.zeros(len(chunks), rtx.MESHINFO)
@@ -91,7 +98,8 @@ def random_scene(rtx, seed):
     ns = int(rng.integers(0, 5))
     sph = np.zeros(ns, rtx.SPHERE)
     for s in sph:
-        s["position"] = rng.uniform([-4, 0, -8], [4, 3, 4]); s["radius"] = float(10.0 ** rng.uniform(-1, 0.6))
+        s["position"] = rng.uniform([-4, 0, -8], [4, 3, 4]) + shift
+        s["radius"] = float(10.0 ** rng.uniform(-1, 0.6)) if rng.random() < 0.9 else 0.0
         s["material"]["colour"] = (*rng.uniform(0.2, 1, 3), 1); s["material"]["specularColour"] = (1, 1, 1, 1)
         s["material"]["emissionStrength"] = float(rng.choice([0, 2])); s["material"]["emissionColour"] = (1, 1, 1, 1)
         s["material"]["smoothness"] = float(rng.choice([0, 1])); s["material"]["specularProbability"] = float(rng.choice([0, 1]))
@@ -102,7 +110,7 @@ def random_scene(rtx, seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "24"))))   # RTX_FUZZ_SEEDS=400 for a soak run
 def test_random_scene_matches_the_oracle(rtx, oracle, tracer, seed):
     b = random_scene(rtx, seed)
-    kernel = (0, 1, 3)[seed % 3]
+    kernel = (0, 1, 3, 1, 2, 1, -1)[seed % 7]
     acc, last = run_gpu(tracer, b, seed, 2, kernel=kernel)
     rays = tracer.stats()["rays"]
     want_acc, want_last, cnt = oracle.render(*b, seed, 2, accel=True)
