@@ -1,7 +1,7 @@
 """Randomised differential test: scenes built straight into the reference's buffer layouts — triangle soups from 1e-2 to
 100 units, slivers, exact duplicates and coplanar stacks (dst ties), integer-grid quads (rays through shared edges), zero-area
 and NaN triangles, chunk boxes that are tight (the reference's), loose or too tight (FLAT_CHUNKS must cut the same triangles
-off), spheres around the camera — with random tracer settings.  GPU (each kernel in turn) == oracle, bit for bit, and the
+off), spheres around the camera — with random tracer settings and random tuning knobs (stack spill, loop thresholds, leaf size, builder).  GPU (each kernel in turn) == oracle, bit for bit, and the
 oracle's search tree == its literal loop on the same input."""
 import os
 
@@ -111,8 +111,20 @@ def random_scene(rtx, seed):
 def test_random_scene_matches_the_oracle(rtx, oracle, tracer, seed):
     b = random_scene(rtx, seed)
     kernel = (0, 1, 3, 1, 2, 1, -1)[seed % 7]
-    acc, last = run_gpu(tracer, b, seed, 2, kernel=kernel)
-    rays = tracer.stats()["rays"]
+    rng = np.random.default_rng(seed)
+    knobs = {"stream_stack": int(rng.choice([4, 9, 37])), "node_min": int(rng.choice([1, 6, 24, 64])), "tiles_per_fetch": int(rng.choice([1, 2, 5])),
+             "max_leaf": int(rng.choice([1, 2, 4])), "full_sort": int(rng.integers(0, 2)), "frame_batch": int(rng.choice([0, 1])),
+             "refill_min": int(rng.choice([1, 16, 40])), "bvh_reinsert": int(rng.choice([0, 0, 2]))}
+    defaults = {"stream_stack": 37, "node_min": 6, "tiles_per_fetch": 2, "max_leaf": 2, "full_sort": 0, "frame_batch": 0, "refill_min": 16,
+                "bvh_reinsert": 0}
+    for k, v in knobs.items():
+        tracer.set_option(k, v)
+    try:
+        acc, last = run_gpu(tracer, b, seed, 2, kernel=kernel, shade_threshold=int(rng.choice([1, 24, 48, 64])))
+        rays = tracer.stats()["rays"]
+    finally:
+        for k, v in defaults.items():
+            tracer.set_option(k, v)
     want_acc, want_last, cnt = oracle.render(*b, seed, 2, accel=True)
     what = f"fuzz seed {seed} (kernel {kernel}, {len(b[2])} triangles in {len(b[3])} chunks, {len(b[1])} spheres, mode {int(b[0]['intersectMode'])})"
     assert_bitwise(last, want_last, what + ", last frame")
