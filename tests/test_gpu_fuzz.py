@@ -1,6 +1,6 @@
 """Randomised differential test: scenes built straight into the reference's buffer layouts — triangle soups from 1e-2 to
-100 units, slivers, exact duplicates and coplanar stacks (dst ties), integer-grid quads (rays through shared edges), zero-area
-and NaN triangles, chunk boxes that are tight (the reference's), loose or too tight (FLAT_CHUNKS must cut the same triangles
+100 units, slivers, exact duplicates and coplanar stacks (dst ties), integer-grid quads (rays through shared edges), zero-area,
+NaN, infinite and 1e38-sized triangles, chunk boxes that are tight (the reference's), loose or too tight (FLAT_CHUNKS must cut the same triangles
 off), spheres around the camera — with random tracer settings and random tuning knobs (stack spill, loop thresholds, leaf size, builder).  GPU (each kernel in turn) == oracle, bit for bit, and the
 oracle's search tree == its literal loop on the same input."""
 import os
@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _unit(v):
-    n = np.linalg.norm(v, axis=-1, keepdims=True)
-    return np.where(n > 0, v / np.where(n > 0, n, 1), 0).astype(np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        n = np.linalg.norm(v, axis=-1, keepdims=True)
+        return np.where(n > 0, v / np.where(n > 0, n, 1), 0).astype(np.float32)
 
 
 def random_scene(rtx, seed):
@@ -67,6 +68,10 @@ def random_scene(rtx, seed):
             pos[1, 2] = pos[1, 1] = pos[1, 0]     # a point
             if seed % 4 == 0:
                 pos[2, 2, 0] = np.nan
+            elif seed % 4 == 1:
+                pos[3, 0, 1] = np.inf
+            elif seed % 4 == 2:
+                pos[3] = pos[3] * np.float32(3e37)        # products overflow to inf inside RayTriangle
         chunks.append(((pos + shift).astype(np.float32), rng.choice(["tight", "tight", "tight", "loose", "cut"])))
     n = sum(len(c[0]) for c in chunks)
     tris = np.zeros(n, rtx.TRIANGLE)
@@ -76,7 +81,8 @@ def random_scene(rtx, seed):
         k = len(pos)
         t = tris[at:at + k]
         t["posA"], t["posB"], t["posC"] = pos[:, 0], pos[:, 1], pos[:, 2]
-        face = _unit(np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]))
+        with np.errstate(invalid="ignore", over="ignore"):
+            face = _unit(np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]))
         for f in ("normalA", "normalB", "normalC"):
             t[f] = _unit(face + rng.uniform(-0.3, 0.3, (k, 3)).astype(np.float32)) if rng.random() < 0.8 else 0.0
         mi = infos[ci]
@@ -87,12 +93,12 @@ def random_scene(rtx, seed):
         mat["emissionStrength"] = float(rng.choice([0, 0, 3]))
         mat["smoothness"] = float(rng.choice([0, 0.5, 1])); mat["specularProbability"] = float(rng.choice([0, 0.3, 1]))
         mat["flag"] = int(rng.choice([0, 0, 1, 2]))
-        with np.errstate(invalid="ignore"):
+        with np.errstate(invalid="ignore", over="ignore"):
             lo, hi = np.nanmin(pos.reshape(-1, 3), axis=0), np.nanmax(pos.reshape(-1, 3), axis=0)
-        if policy == "loose":
-            lo, hi = lo - 0.5, hi + 0.5
-        elif policy == "cut":
-            mid = 0.5 * (lo + hi); lo, hi = mid - 0.3 * (hi - lo), mid + 0.3 * (hi - lo)
+            if policy == "loose":
+                lo, hi = lo - 0.5, hi + 0.5
+            elif policy == "cut":
+                mid = 0.5 * (lo + hi); lo, hi = mid - 0.3 * (hi - lo), mid + 0.3 * (hi - lo)
         mi["boundsMin"], mi["boundsMax"] = lo, hi
         at += k
     ns = int(rng.integers(0, 5))
