@@ -99,3 +99,42 @@ def test_manager_device_geometry_flag(rtx, tracer):
     mgr2.Start()
     got = mgr2.OnRenderImage(frames=2)
     assert_bitwise(got, want, "manager with deviceGeometry")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_transforms_device_geometry_equals_host_marshal(rtx, tracer, seed):
+    """Random poses per mesh — arbitrary unit quaternions (and a slightly non-unit one), non-uniform, negative and zero scales,
+    translations up to 1e3 — through the device pipeline: world triangles and chunk bounds equal the host marshal's bytes,
+    and the image equals the host path's (the second pose set goes through the BVH refit)."""
+    rng = np.random.default_rng(500 + seed)
+    mgr = rtx.scenes.mesh_test_scene(64, 48)
+
+    def pose():
+        for i, me in enumerate(mgr.meshes):
+            q = rng.normal(size=4)
+            q = q / np.linalg.norm(q) * (1.0001 if i == 1 else 1.0)
+            s = 10.0 ** rng.uniform(-1.5, 0.8, 3) * rng.choice([1, 1, 1, -1], 3)
+            if i == 2 and seed % 3 == 0:
+                s[int(rng.integers(0, 3))] = 0.0
+            big = 1e3 if seed % 4 == 3 else 6.0
+            me.transform = rtx.host.Transform(position=tuple(rng.uniform(-big, big, 3)), rotation=tuple(q), lossyScale=tuple(s))
+
+    pose()
+    upload_local(tracer, mgr)
+    for round_ in range(2):
+        if round_ == 1:
+            pose()
+            tracer.set_mesh_transforms(mgr.build_transforms())      # same topology: refit
+        _, _, tris, infos = mgr.build_buffers()
+        tracer.reset_accum()
+        tracer.render(round_, 1)
+        got = tracer.read_last_frame()
+        dtris, dinfos = tracer.read_world_geometry()
+        for k in tris.dtype.names:
+            assert bytes_equal(dtris[k], tris[k]), f"seed {seed} round {round_}: triangles.{k} differ"
+        for k in ("boundsMin", "boundsMax"):
+            assert bytes_equal(dinfos[k], infos[k]), f"seed {seed} round {round_}: meshinfo.{k} differ"
+        _, want = run_gpu(tracer, mgr.build_buffers(), round_, 1, kernel=-1)
+        assert_bitwise(got, want, f"seed {seed} round {round_}: image through the device pipeline")
+        if round_ == 0:
+            upload_local(tracer, mgr)                                # back to the local-mesh path for the refit round
