@@ -232,9 +232,10 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBPS, 5), "traffic": traffic,
-                    "kernel": "k_trace<false,false,true>" if args.rng == "philox" else
-                              {0: "k_trace<false,false,false>", 1: "k_stream<false>", 2: "k_pool<false>", 3: "k_wave<false>"}.get(
-                                  st.get("autoKernel", -1) if args.kernel < 0 else args.kernel, "k_trace<false,false,false>"), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl, "launches": launches,
+                    "kernel": ({1: "k_stream<false,true>"} if args.rng == "philox" else
+                               {0: "k_trace<false,false,false>", 1: "k_stream<false>", 2: "k_pool<false>", 3: "k_wave<false>"}).get(
+                                  st.get("autoKernel", -1) if args.kernel < 0 else args.kernel,
+                                  "k_trace<false,false,true>" if args.rng == "philox" else "k_trace<false,false,false>"), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl, "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "per_ray": {"nodes": round(sc["nodeVisits"] / max(sc["rays"], 1), 2),
                                 "tris": round(sc["triTests"] / max(sc["rays"], 1), 2),

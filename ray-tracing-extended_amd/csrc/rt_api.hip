@@ -407,7 +407,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     }
     const bool philox = c->params.rngMode == RT_RNG_PHILOX;         // served by k_trace's Philox instantiation only
     if (philox && var == Variant::Flat) return fail(c, -2, "the flat validation kernel implements the PCG stream only");
-    const bool stream = !philox && kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;
+    const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;       // PCG or Philox instantiation
     const bool pooled = !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
     const bool waved = !philox && kernel == 3 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
@@ -432,7 +432,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
                    : pooled ? (var == Variant::Fast ? (const void*)rtk::k_pool<false> : (const void*)rtk::k_pool<true>)
                    : waved ? (var == Variant::Fast ? (const void*)rtk::k_wave<false> : (const void*)rtk::k_wave<true>)
-                   : stream ? (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>)
+                   : stream ? (philox ? (var == Variant::Fast ? (const void*)rtk::k_stream<false, true> : (const void*)rtk::k_stream<true, true>)
+                                     : (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>))
                    : philox ? (var == Variant::Fast ? (const void*)rtk::k_trace<false, false, true> : (const void*)rtk::k_trace<true, false, true>)
                             : (var == Variant::Fast ? (const void*)rtk::k_trace<false, false> : (const void*)rtk::k_trace<true, false>);
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -523,8 +524,11 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
             if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_pool<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
             else                      hipLaunchKernelGGL((rtk::k_pool<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
         } else if (stream) {
-            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
-            else                      hipLaunchKernelGGL((rtk::k_stream<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+            if (philox) {
+                if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+                else                      hipLaunchKernelGGL((rtk::k_stream<true, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+            } else if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
+            else                             hipLaunchKernelGGL((rtk::k_stream<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
         } else if (philox) {
             if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_trace<false, false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
             else                      hipLaunchKernelGGL((rtk::k_trace<true, false, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
@@ -579,7 +583,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
 int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
 {
     if (!c) return -1;
-    const bool eligible = c->opt_kernel < 0 && var != Variant::Flat && c->have_params && c->params.rngMode == RT_RNG_PCG
+    const bool eligible = c->opt_kernel < 0 && var != Variant::Flat && c->have_params
                           && c->params.numRaysPerPixel >= 1;
     if (!eligible) {
         const int kernel = c->opt_kernel < 0 ? 0 : c->opt_kernel;
@@ -736,6 +740,7 @@ int rt_set_params(rt_ctx* c, const rt_params* p)
     if (p->intersectMode != RT_INTERSECT_FLAT_CHUNKS && p->intersectMode != RT_INTERSECT_BRUTE) return fail(c, -2, "unknown intersectMode %d", p->intersectMode);
     // a moved camera keeps the previous frame's tile order and kernel choice as predictors; the next launch re-measures the costs
     if (!c->have_params || std::memcmp(&c->params, p, sizeof *p) != 0) c->tile_order_stale = true;
+    if (c->have_params && c->params.rngMode != p->rngMode) c->auto_choice = -1;      // the kernels' relative speed depends on the RNG
     c->params = *p; c->have_params = true;
     return 0;
 }

@@ -34,7 +34,7 @@ struct StreamArgs {
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
-template <bool COUNT>
+template <bool COUNT, bool PHILOX = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t mode = A.tile_sync ? kModeWait : kModeShade;   // every lane starts by asking for a pixel (or the wave for a tile)
     bool fresh = false;                 // the lane was just given a pixel: its first camera ray is due
     int px = -1, ly = 0;                // current pixel (px < 0: none)
-    uint32_t rng = 0;
+    typename std::conditional<PHILOX, rtm::PhiloxRng, uint32_t>::type rng;        // RT_RNG_PCG: the reference's stream; RT_RNG_PHILOX: counter-based
+    if constexpr (PHILOX) rng.init(0u, 0u); else rng = 0u;
     int sample = 0, bounce = 0;
     v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
     RaySlab slab = make_slab(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
         if (!(x < p.width && yy < F.nrows)) return false;
         px = x; ly = yy; wave_fi = fi;
-        rng = ((uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x) + (uint32_t)(F.frame + (int)fi) * 719393u;   // :361-362
+        const uint32_t pixelIndex = (uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x;
+        if constexpr (PHILOX) rng.init(pixelIndex, (uint32_t)(F.frame + (int)fi));
+        else rng = pixelIndex + (uint32_t)(F.frame + (int)fi) * 719393u;                    // :361-362
         total = rtm::mk(0.f, 0.f, 0.f);
         sample = 0; live = false;
         return true;
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (x < p.width && yy < F.nrows) {
                                 px = x; ly = yy;
                                 const int y = F.row0 + (yy >> 3) * F.row_stride + (yy & 7);
-                                rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;      // :361-362
+                                if constexpr (PHILOX) rng.init((uint32_t)y * W + (uint32_t)x, (uint32_t)F.frame);
+                                else rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;      // :361-362
                                 total = rtm::mk(0.f, 0.f, 0.f);
                                 sample = 0;
                                 need_ray = true;        // (numRaysPerPixel < 1 is routed to k_trace by the host)

@@ -232,9 +232,11 @@ def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene):
     params = params.copy()
     params["rngMode"] = 1
     b = (params, spheres, tris, infos)
-    for kernel in (0, 2):                       # kernel option 2 is served by the same Philox instantiation of k_trace
-        acc, last = run_gpu(tracer, b, 3, 2, kernel=kernel)
-        want, want_last, _ = oracle.render(*b, 3, 2)
+    want, want_last, _ = oracle.render(*b, 3, 2)
+    for kernel in (0, 1, 2, -1):                # k_trace<PHILOX>, k_stream<PHILOX>; option 2 falls back to k_trace's; automatic choice
+        acc, last = run_gpu(tracer, b, 3, 2 if kernel >= 0 else 5, kernel=kernel)
+        if kernel < 0:
+            want, want_last, _ = oracle.render(*b, 3, 5)
         assert_bitwise(last, want_last, f"philox {scene} last frame (kernel option {kernel})")
         assert_bitwise(acc, want, f"philox {scene} accum (kernel option {kernel})")
     pcg, _ = run_gpu(tracer, (m.build_buffers()[0], spheres, tris, infos), 3, 2)
