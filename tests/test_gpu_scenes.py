@@ -161,9 +161,9 @@ def test_full_size_headline_frame_vs_oracle(rtx, oracle, tracer):
     assert rays == cnt["rays"] > 200_000_000
 
 
-@pytest.mark.parametrize("name", ["Chess", "Knight", "Reflective_Balls", "Balls_Outdoors"])
+@pytest.mark.parametrize("name", ["Chess", "Knight", "Reflective_Balls", "Balls_Outdoors", "Suzanne", "Thumbnail"])
 def test_reference_scene_full_hd_vs_oracle(rtx, oracle, tracer, name):
-    """The reference's own scenes at 1920x1080 with their serialized settings' bounce count, 1 ray per pixel, frame 3."""
+    """All six of the reference's own scenes at 1920x1080 with their serialized settings' bounce count, 1 ray per pixel, frame 3."""
     from rtx_amd import unity_scene
     m = unity_scene.load_scene_npz(os.path.join(GOLDEN, "scenes", name + ".npz"), 1920, 1080)
     m.numRaysPerPixel = 1
