@@ -1,0 +1,12 @@
+/* Link-time stand-ins for librt_mi355x (our own C-ABI) so that the compiled host can be linked and run under the CPU sanitizers:
+   the run exercises the scene loader and the marshal only; every device call reports failure. */
+#include <stddef.h>
+struct rt_ctx; 
+int rt_set_params(struct rt_ctx* c, const void* p) { return -1; }
+int rt_upload_spheres(struct rt_ctx* c, const void* p, int n) { return -1; }
+int rt_upload_triangles(struct rt_ctx* c, const void* p, int n) { return -1; }
+int rt_upload_meshinfo(struct rt_ctx* c, const void* p, int n) { return -1; }
+int rt_render(struct rt_ctx* c, int a, int b) { return -1; }
+int rt_reset_accum(struct rt_ctx* c) { return -1; }
+int rt_read_accum(struct rt_ctx* c, float* f, size_t n) { return -1; }
+const char* rt_last_error(struct rt_ctx* c) { return "stub"; }
