@@ -45,6 +45,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // resident whatever the tree depth.
     const int cap = F.stack_cap;
     uint32_t* const gstk = F.gstack ? F.gstack + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
+    int sp = 0;
+    // pop: plain ds_read when nothing can spill (wave-uniform test); otherwise an LDS read from a clamped slot, replaced by
+    // the global entry for the rare lane above the LDS part (a select between the two address spaces would turn every pop
+    // into a flat load)
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        if (gstk == nullptr) return stk[sp * 64];
+        uint32_t v = stk[min(sp, cap - 1) * 64];
+        asm volatile("" : "+v"(v));          // keep this a ds_read: do not fold it into a pointer select with the load below
+        if (sp >= cap) v = gstk[(size_t)(sp - cap) * F.gstack_stride];
+        return v;
+    };
     Counters cnt = {};
     const rt_params& p = F.p;
     const float* M = p.camLocalToWorld;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     int sample = 0, bounce = 0;
     v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
     RaySlab slab = make_slab(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
-    uint32_t cur = kNone; int sp = 0;
+    uint32_t cur = kNone;
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
     unsigned int wave_fi = 0;           // frame (offset) of the tile this wave is working on
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (t1 < INF) { if (sp < cap) stk[sp * 64] = c1; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c1; ++sp; }
                         }
                         if (t0 < INF) cur = c0;
-                        else if (sp > 0) { --sp; cur = (sp < cap) ? stk[sp * 64] : gstk[(size_t)(sp - cap) * F.gstack_stride]; }
+                        else if (sp > 0) cur = pop();
                         else { cur = kNone; mode = kModeShade; }
                     }
                 }
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                         }
                     }
-                    if (sp > 0) { --sp; cur = (sp < cap) ? stk[sp * 64] : gstk[(size_t)(sp - cap) * F.gstack_stride]; }
+                    if (sp > 0) cur = pop();
                     else { cur = kNone; mode = kModeShade; }
                 }
                 if (ballot_(mode == kModeTrav) == 0) break;
