@@ -141,7 +141,9 @@ __device__ __forceinline__ bool ray_triangle(v3 o, v3 d, v3 A, v3 eAB, v3 eAC, v
     v3 ao = o - A;
     v3 dao = rtm::cross(ao, d);
     float det = -rtm::dot(d, n);
-    float inv = 1.0f / det;
+    // 1/det: exact for det in [2^-100, 2^100]; a det below 1e-6 (or NaN) never hits, so its reciprocal is never looked at
+    float inv = rtm::rcp_mid(det);
+    if (det > 0x1p100f) { RT_COLD_PATH(); inv = 1.0f / det; }
     dst = rtm::dot(ao, n) * inv;
     u = rtm::dot(eAC, dao) * inv;
     v = -rtm::dot(eAB, dao) * inv;
@@ -166,7 +168,7 @@ struct RaySlab {
 __device__ __forceinline__ RaySlab make_slab(v3 o, v3 d)
 {
     RaySlab r;
-    r.inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.inv = rtm::mk(rtm::rcp_(d.x), rtm::rcp_(d.y), rtm::rcp_(d.z));
     r.oinv = rtm::mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
     r.nx = d.x < 0.0f ? 48u : 0u;
     r.ny = d.y < 0.0f ? 64u : 16u;
@@ -457,7 +459,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
 
                 float pr = rtm::fmax_(rayColour.x, rtm::fmax_(rayColour.y, rayColour.z));   // :338-342
                 if (rtm::random_value(rng) >= pr) path_done = true;
-                else { float ip = 1.0f / pr; rayColour = rayColour * ip; }
+                else { float ip = rtm::rcp_(pr); rayColour = rayColour * ip; }
             }
             ++bounce;
             if (bounce > p.maxBounceCount) path_done = true;                           // loop bound :305

@@ -27,10 +27,65 @@ __device__ __forceinline__ v3 cross(v3 a, v3 b)
 {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ v3 normalize(v3 a)
+// ---- correctly rounded 1/x, sqrt(x), a/b from the hardware estimates + FMA corrections ---------------------------------
+// The frozen semantics are IEEE `/` and `sqrt`.  hipcc's correctly rounded expansions cost ~12 and ~17 VALU instructions; inside
+// the guard ranges the short sequences below return the same bits — verified on gfx950 for EVERY float32 input of rcp_mid and
+// sqrt_mid and for 4e10 random and structured quotients of div_mid (tools/exactmath/verify.hip; Markstein's quotient theorem
+// covers the rest once r = RN(1/b)); outside the guards the compiler's IEEE sequence runs, so every input gives IEEE bits.
+__device__ __forceinline__ bool mid_range(float x)          // |x| in [2^-100, 2^100]; false for NaN, inf, 0, denormals
 {
-    float len = __builtin_sqrtf(dot(a, a));
-    return mk(a.x / len, a.y / len, a.z / len);
+    const float ax = __builtin_fabsf(x);
+    return ax >= 0x1p-100f && ax <= 0x1p100f;
+}
+__device__ __forceinline__ float rcp_mid(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float sqrt_mid(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
+}
+// The IEEE fallbacks must stay behind real branches: both sides are speculatable, and if-converted they would run for every
+// lane next to the short sequence.  An (empty) volatile asm cannot be speculated, so the block it sits in stays a block.
+#define RT_COLD_PATH() asm volatile("")
+__device__ __forceinline__ float rcp_(float x)                                                         // == 1.0f / x
+{
+    float r = rcp_mid(x);
+    if (!mid_range(x)) { RT_COLD_PATH(); r = 1.0f / x; }
+    return r;
+}
+__device__ __forceinline__ float sqrt_(float x)                                                        // == sqrtf(x)
+{
+    float r = sqrt_mid(x);
+    if (!(x >= 0x1p-100f && x <= 0x1p100f)) { RT_COLD_PATH(); r = __builtin_sqrtf(x); }
+    return r;
+}
+// a / b with r = rcp_mid(b): valid for |b| in [2^-60, 2^60] and |a| in [2^-60, 2^60] (quotient in [2^-120, 2^120])
+__device__ __forceinline__ float div_mid(float a, float b, float r)
+{
+    const float q = a * r;
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, r, q);
+}
+__device__ __forceinline__ v3 normalize(v3 a)              // == a / sqrt(dot(a, a)), three IEEE quotients
+{
+    const float len = sqrt_(dot(a, a));
+    // a zero component gives the same signed zero (len > 0); a non-zero one must not be below 2^-60 (|bits| - 1 wraps for 0)
+    const uint32_t kLo = (67u << 23) - 1u;
+    const uint32_t mx = (f2u(a.x) & 0x7FFFFFFFu) - 1u, my = (f2u(a.y) & 0x7FFFFFFFu) - 1u, mz = (f2u(a.z) & 0x7FFFFFFFu) - 1u;
+    const float r = rcp_mid(len);
+    const float qx = div_mid(a.x, len, r), qy = div_mid(a.y, len, r), qz = div_mid(a.z, len, r);
+    v3 q = mk(a.x == 0.0f ? a.x : qx, a.y == 0.0f ? a.y : qy, a.z == 0.0f ? a.z : qz);
+    if (!(len >= 0x1p-60f && len <= 0x1p60f && min(min(mx, my), mz) >= kLo)) {
+        RT_COLD_PATH();
+        q = mk(a.x / len, a.y / len, a.z / len);
+    }
+    return q;
 }
 __device__ __forceinline__ v3 lerp(v3 a, v3 b, float t)
 {
@@ -196,7 +251,7 @@ __device__ __forceinline__ float random_normal(R& state)
 {
     const float TWO_PI = 2.0f * 3.1415926f;
     float theta = TWO_PI * random_value(state);
-    float rho = __builtin_sqrtf(-2.0f * log_(random_value(state)));
+    float rho = sqrt_(-2.0f * log_(random_value(state)));
     return rho * cos_(theta);
 }
 // RayTracing.shader:216-223
@@ -216,7 +271,7 @@ __device__ __forceinline__ void random_point_in_circle(R& state, float& px, floa
     float angle = random_value(state) * 2.0f * PI;
     float sn, cs;
     sincos_(angle, sn, cs);
-    float s = __builtin_sqrtf(random_value(state));
+    float s = sqrt_(random_value(state));
     px = cs * s;
     py = sn * s;
 }

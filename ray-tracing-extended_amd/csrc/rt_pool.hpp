@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                     rayColour = rayColour * rtm::lerp(colour, rtm::mk(mspec.x, mspec.y, mspec.z), specF);
                     float pr = rtm::fmax_(rayColour.x, rtm::fmax_(rayColour.y, rayColour.z));   // :338-342
                     if (rtm::random_value(rng) >= pr) path_done = true;
-                    else { float ip = 1.0f / pr; rayColour = rayColour * ip; }
+                    else { float ip = rtm::rcp_(pr); rayColour = rayColour * ip; }
                 }
                 ++bounce;
                 if (bounce > p.maxBounceCount) path_done = true;               // loop bound :305
