@@ -120,15 +120,31 @@ __device__ __forceinline__ bool ray_bounding_box(v3 o, v3 inv, v3 bmin, v3 bmax)
     return tNear <= tFar;
 }
 
-// RaySphere — RayTracing.shader:120-146
-__device__ __forceinline__ bool ray_sphere(v3 o, v3 d, float a, v3 centre, float radius, float& dst)
+// RaySphere — RayTracing.shader:120-146.  a = dot(dir, dir) and the denominator 2a are the same for every sphere a ray meets:
+// its correctly rounded reciprocal is taken once per ray, and the quotient (-b - sqrt(disc)) / (2a) is Markstein's (rt_math.hpp)
+// when both operands are in the verified range, the compiler's IEEE division otherwise — the same bits either way.
+struct SphereA { float a, den, rden; bool den_ok; };
+__device__ __forceinline__ SphereA sphere_a(float a)
+{
+    SphereA s; s.a = a; s.den = 2.0f * a;
+    s.den_ok = s.den >= 0x1p-60f && s.den <= 0x1p60f;
+    s.rden = rtm::rcp_mid(s.den);
+    return s;
+}
+__device__ __forceinline__ bool ray_sphere(v3 o, v3 d, const SphereA& sa, v3 centre, float radius, float& dst)
 {
     v3 oc = o - centre;
     float b = 2.0f * rtm::dot(oc, d);
     float c = rtm::dot(oc, oc) - radius * radius;
-    float disc = b * b - 4.0f * a * c;
+    float disc = b * b - 4.0f * sa.a * c;
     if (disc >= 0.0f) {
-        dst = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        const float num = -b - rtm::sqrt_(disc);
+        const float an = __builtin_fabsf(num);
+        const float q0 = num * sa.rden;
+        float q = __builtin_fmaf(__builtin_fmaf(-q0, sa.den, num), sa.rden, q0);
+        q = (num == 0.0f) ? q0 : q;                               // a zero numerator keeps its sign through the product
+        if (!(sa.den_ok && (num == 0.0f || (an >= 0x1p-60f && an <= 0x1p60f)))) { RT_COLD_PATH(); q = num / sa.den; }
+        dst = q;
         return dst >= 0.0f;
     }
     return false;
@@ -234,11 +250,12 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
 
     // CalculateRayCollision :263-273 — buffer order, strict '<' (first sphere wins ties)
     const float a = rtm::dot(d, d);
+    const SphereA sa = sphere_a(a);
     for (int i = 0; i < S.ns; ++i) {
         float4 s = S.sph_geom[i];
         float dst;
         if (COUNT) cnt.sph++;
-        if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+        if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
     }
 
     if (S.nn > 0) {
@@ -311,10 +328,11 @@ __device__ __forceinline__ Hit closest_hit_flat(const DeviceScene& S, int inters
 {
     Hit best; best.t = __builtin_inff(); best.id = kNone; best.u = 0.f; best.v = 0.f;
     const float a = rtm::dot(d, d);
+    const SphereA sa = sphere_a(a);
     for (int i = 0; i < S.ns; ++i) {
         float4 s = S.sph_geom[i];
         float dst;
-        if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+        if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
     }
     const v3 inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     nrm_out = rtm::mk(0.f, 0.f, 0.f); chunk_out = 0;

@@ -147,11 +147,12 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                             cnt.rays++;
                             best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
                             const float a = rtm::dot(d, d);
+                            const SphereA sa = sphere_a(a);
                             for (int i = 0; i < S.ns; ++i) {
                                 const float4 s = S.sph_geom[i];
                                 float dst;
                                 if (COUNT) cnt.sph++;
-                                if (ray_sphere(o, d, a, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+                                if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
                             }
                             if (S.nn > 0) {
                                 slab = make_slab(o, d);

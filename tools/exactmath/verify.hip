@@ -33,10 +33,12 @@ __global__ void k_div(unsigned long long* bad, uint32_t* first_bad, uint32_t rou
         if (mode == 1) a = b * (float)(int)(1u + pcg(s) % 4096u);                           // exact multiples
         else if (mode == 2) a = u2f(with_exp(ua, (ub >> 23) & 0xFFu));                        // same exponent: quotient in (0.5, 2)
         else if (mode == 3) { const float k = (float)(int)(1u + pcg(s) % 1000u); a = u2f(f2u(b * k) + (pcg(s) % 5u) - 2u); }   // next to multiples
+        if ((it & 63u) == 63u) a = u2f(ua & 0x80000000u);                                     // +0 / -0 numerators (sign through the product)
         const float aa = __builtin_fabsf(a), ab = __builtin_fabsf(b);
-        if (!(aa >= 0x1p-60f && aa <= 0x1p60f && ab >= 0x1p-60f && ab <= 0x1p60f)) continue;
+        if (!((a == 0.0f || (aa >= 0x1p-60f && aa <= 0x1p60f)) && ab >= 0x1p-60f && ab <= 0x1p60f)) continue;
         ++tested;
-        if (!same(div_mid(a, b, rcp_mid(b)), a / b)) { if (atomicAdd(&bad[2], 1ull) == 0) { first_bad[2] = f2u(a); first_bad[3] = f2u(b); } }
+        const float r = rcp_mid(b);
+        if (!same(a == 0.0f ? a * r : div_mid(a, b, r), a / b)) { if (atomicAdd(&bad[2], 1ull) == 0) { first_bad[2] = f2u(a); first_bad[3] = f2u(b); } }
     }
     atomicAdd(&bad[5], tested);
 }
