@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+L1_PEAK_GBPS = 256 * 64 * 2.4          # 256 CUs x 64 B/clk x 2.4 GHz = 39.3 TB/s of vector L1 bandwidth
 PEAK_HBM_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 NODE_BYTES, TRI_BYTES, SPHERE_BYTES, HIT_BYTES, PIXEL_BYTES = 128, 48, 16, 64 + 48, 48
 
@@ -227,7 +228,7 @@ def main():
                 tj = json.load(open(tf))
                 key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}_x{fpl}"
                 traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None   # measured for the N=1 launch
-                pmc_extra = {k: tj.get(key, {}).get(k) for k in ("l2_hit_rate", "valu_active_frac_per_simd", "ta_busy_frac", "valu_lane_utilisation")} if world == 1 else None
+                pmc_extra = {k: tj.get(key, {}).get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_active_frac_per_simd", "ta_busy_frac", "td_busy_frac", "valu_lane_utilisation")} if world == 1 else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -248,7 +249,12 @@ def main():
                                               "triangle": round(sc["triTests"] / (kernel_ms_rank0 / 1e3), 0),
                                               "sphere": round(sc["sphereTests"] / (kernel_ms_rank0 / 1e3), 0)},
                     "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]},
-                    "limiter": "VALU issue (cache-resident working set): see pmc", "pmc": pmc_extra}
+                    # the working set is cache-resident: what the traversal really loads is the vector L1 -> VGPR path
+                    # (64 B/clk per CU); a wave's load occupies it for all 64 lanes, so the lane-utilisation-corrected figure is given too
+                    "vector_l1": {"achieved": round(ach, 2), "peak": L1_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / L1_PEAK_GBPS, 5),
+                                  "frac_counting_idle_lanes": round(ach / L1_PEAK_GBPS / max(sc["phaseLanes"][0] / max(64 * sc["phaseExecs"][0], 1), 1e-9), 5)
+                                  if sc["phaseExecs"][0] else None},
+                    "limiter": "VALU issue and the vector-memory return path (TD) together; cache-resident working set: see pmc", "pmc": pmc_extra}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(rtx, buffers)

@@ -14,7 +14,7 @@ echo "[profile] stats done"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
             "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" \
-            "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum"; do
+            "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum" "TD_TD_BUSY_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
   name=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 "$R/bench.py" $ARGS > "$OUT/pmc_$name.log" 2>&1 || echo "[profile] pass '$pass' failed"
   echo "[profile] pmc $pass done"

@@ -59,6 +59,10 @@ if "GRBM_GUI_ACTIVE" in c:
         d["valu_active_frac_per_simd"] = c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] * 32)
     if "TA_TA_BUSY_sum" in c:
         d["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] * 32)
+    if "TD_TD_BUSY_sum" in c:
+        d["td_busy_frac"] = c["TD_TD_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] * 32)
+if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
+    d["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1)
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     d["hbm_bytes_per_full_launch"] = c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024
 out["derived"] = d
