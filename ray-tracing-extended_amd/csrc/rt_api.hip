@@ -91,6 +91,7 @@ struct rt_ctx {
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
     int opt_tiles_per_fetch = 2;    // k_stream: measured best (1: 10.24, 2: 10.42, 3: 10.29, 4: 10.06, 8: 9.20 Grays/s)
+    int opt_stream_tile = 2;        // k_stream: log2 of the frames interleaved in a wave (0: 8x8 pixels x 1 frame, 2: 4x4 x 4, 4: 2x2 x 16)
     int opt_node_min = 6;           // k_stream: measured best 4..8 on the 100k-triangle workload (+7 % over 1)
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 0;          // 1: sort all four children; 0: nearest first only (measured +1 %)
@@ -510,7 +511,14 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < n_frames; ) {
-        const int nb = batch > 1 ? std::min(batch, n_frames - i) : 1;
+        int nb = batch > 1 ? std::min(batch, n_frames - i) : 1;
+        // k_stream, frame-interleaved sub-tiles: a wave = (4x4 or 2x2 pixels) x (4 or 16 frames); launches take whole frame
+        // groups, the remainder of the render goes out as 8x8 x 1 items
+        A.fg_log2 = 0;
+        if (stream_tiles && c->opt_stream_tile > 0 && nb >= (1 << c->opt_stream_tile)) {
+            nb -= nb % (1 << c->opt_stream_tile);
+            A.fg_log2 = c->opt_stream_tile;
+        }
         F.frame = first_frame + i;
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
         F.out_frame = nb > 1 ? c->d_batch.p : c->d_frame.p;
@@ -849,6 +857,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "tiles_per_fetch")) { if (value < 1 || value > 16) return fail(c, -2, "tiles_per_fetch must be in [1,16]"); c->opt_tiles_per_fetch = value; }
     else if (!std::strcmp(name, "node_min")) { if (value < 1 || value > 64) return fail(c, -2, "node_min must be in [1,64]"); c->opt_node_min = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
+    else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }
     else return fail(c, -2, "unknown option '%s'", name);

@@ -30,6 +30,10 @@ struct StreamArgs {
     int tiles_per_fetch;        // tile_sync: a wave reserves this many consecutive work items at a time; a lane that finishes its
                                 // pixel of one moves on to its position in the next without waiting for the slower lanes
     int tile_sync;              // 1: a wave takes a whole 8x8 tile at a time (coherent lanes), 0: lanes refill pixel by pixel
+    int fg_log2;                // tile_sync: a work item is a sub-tile of 64 >> fg_log2 pixels (8x8, 4x4 or 2x2) in 1 << fg_log2 consecutive
+                                // frames of the launch (0, 2, 4): lane = (frame sub-index, pixel of the sub-tile).  Frames are
+                                // independent (frag :362 seeds by Frame), so the same pixel in 4 or 16 frames gives a wave rays that
+                                // start almost identical and per-lane costs that are identically distributed
 };
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
@@ -84,19 +88,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t cur = kNone;
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
-    unsigned int wave_fi = 0;           // frame (offset) of the tile this wave is working on
+    unsigned int wave_fi = 0;           // frame (offset into the launch) of this lane's pixel
     unsigned long long wave_t0 = 0;
     unsigned int group_base = 0, group_len = 0, kidx = 0;   // items [group_base, group_base + group_len) belong to this wave; kidx: this lane's
 
     // Give this lane its position's pixel of work item `item` = (frame, tile); false when the tile has no pixel there.
+    // Work items: frame group g (1 << fg_log2 frames) x 8x8 tile (costliest first) x sub-tile of the tile.
+    const int fgl = A.fg_log2, pxl = 6 - fgl, swl = pxl >> 1;       // log2 of: frames per item, pixels per sub-tile, sub-tile width
+    const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
+    const unsigned int per_group_ = ntiles_ << fgl;
+    const unsigned int nframes_ = (unsigned)(F.frames_in_launch > 1 ? F.frames_in_launch : 1);
+    const unsigned int nitems_ = per_group_ * ((nframes_ + (1u << fgl) - 1u) >> fgl);
     auto start_pixel = [&](unsigned int item) -> bool {
-        const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-        const unsigned int fi = item / ntiles_;
-        unsigned int tile = item - fi * ntiles_;
+        const unsigned int g = item / per_group_;
+        const unsigned int r = item - g * per_group_;
+        unsigned int tile = r >> fgl;
+        const unsigned int sub = r & ((1u << fgl) - 1u);
         if (F.tile_order) tile = F.tile_order[tile];
-        const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (lane & 7);
-        const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (lane >> 3);
-        if (!(x < p.width && yy < F.nrows)) return false;
+        const unsigned int pix = (unsigned)lane & ((1u << pxl) - 1u);
+        const unsigned int fi = (g << fgl) + ((unsigned)lane >> pxl);
+        const int x = (int)((tile % (unsigned)F.tiles_x) * 8u + ((sub & ((1u << (3 - swl)) - 1u)) << swl) + (pix & ((1u << swl) - 1u)));
+        const int yy = (int)((tile / (unsigned)F.tiles_x) * 8u + ((sub >> (3 - swl)) << swl) + (pix >> swl));
+        if (!(x < p.width && yy < F.nrows && fi < nframes_)) return false;
         px = x; ly = yy; wave_fi = fi;
         const uint32_t pixelIndex = (uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x;
         if constexpr (PHILOX) rng.init(pixelIndex, (uint32_t)(F.frame + (int)fi));
@@ -111,12 +124,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
-            const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-            const unsigned int nitems_ = ntiles_ * (unsigned)(F.frames_in_launch > 1 ? F.frames_in_launch : 1);
             if (F.tile_cost && group_len != 0 && lane == 0) {
                 const uint32_t share = (uint32_t)(((__builtin_readcyclecounter() - wave_t0) >> 6) / group_len);
                 for (unsigned int k = 0; k < group_len; ++k) {
-                    unsigned int t = (group_base + k) % ntiles_;
+                    unsigned int t = ((group_base + k) % per_group_) >> fgl;
                     if (F.tile_order) t = F.tile_order[t];
                     atomicAdd(&F.tile_cost[t], share);
                 }

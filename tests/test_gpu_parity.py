@@ -297,3 +297,38 @@ def test_tile_groups_multi_frame(rtx, oracle, tracer, size, k):
     assert_bitwise(last, want_last, f"{size} k={k}: last frame")
     assert_bitwise(acc, want, f"{size} k={k}: accum")
     assert st["rays"] == cnt["rays"]
+
+
+@pytest.mark.parametrize("stream_tile,size,n,bands", [(2, (93, 61), 9, None), (4, (93, 61), 19, None), (2, (8, 8), 4, None),
+                                                      (4, (5, 130), 16, None), (2, (200, 9), 7, None), (4, (96, 64), 33, (1, 3)),
+                                                      (2, (96, 70), 6, (0, 2))])
+def test_frame_interleaved_sub_tiles(rtx, oracle, tracer, stream_tile, size, n, bands):
+    """k_stream with a wave = (4x4 or 2x2 pixels) x (4 or 16 frames of the launch): whole frame groups in one launch, the
+    remainder as 8x8 x 1 items; partial tiles, rows in interleaved bands, frame counts that are not multiples of the group.
+    Image, last frame and ray count are the oracle's (frames are independent: frag :362; the accumulation stays ordered)."""
+    b = rtx.scenes.mesh_test_scene(*size).build_buffers()
+    W, H = size
+    tracer.set_option("stream_tile", stream_tile)
+    try:
+        if bands:
+            params, spheres, tris, infos = b
+            tracer.set_option("kernel", 1)
+            tracer.set_params(params)
+            tracer.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+            tracer.set_bands(*bands)
+            tracer.reset_accum()
+            tracer.render(2, n)
+            acc, last = tracer.read_accum(), tracer.read_last_frame()
+            rows = rtx.distributed.band_rows(H, bands[1], bands[0])
+        else:
+            acc, last = run_gpu(tracer, b, 2, n, kernel=1)
+            rows = list(range(H))
+        st = tracer.stats()
+    finally:
+        tracer.set_option("stream_tile", 2)
+        tracer.set_rows(0, H)
+    want, want_last, cnt = oracle.render(*b, 2, n)
+    assert_bitwise(last, want_last[rows], f"stream_tile {stream_tile} {size} x{n}: last frame")
+    assert_bitwise(acc, want[rows], f"stream_tile {stream_tile} {size} x{n}: accum")
+    if not bands:
+        assert st["rays"] == cnt["rays"]
