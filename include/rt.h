@@ -195,6 +195,10 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch; a lane that finishes its pixel of one tile moves on to its
  *                     position in the next tile of the group instead of idling until the tile's slowest pixel is done (default 2)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
+ *   "stream_tile"     k_stream: frames interleaved in a wave, as log2: 0 = 8x8 pixels of one frame, 2 = 4x4 pixels x 4 frames of the
+ *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)
+ *   "compact_nodes"   k_trace / k_stream: 1 = traverse the f16 form of the BVH nodes (5 loads per node visit, default), 0 = the
+ *                     f32 form (7 loads)
  *   "pool_stack", "trav_min_lanes"   k_pool: LDS stack entries per lane; in-flight lanes below which TRAVERSE is left
  *   "refill_min", "wave_trav_min", "wave_node_min"   k_wave: idle lanes that trigger a refill from the pending list (16);
  *                     in-flight lanes below which TRAVERSE is left once the list is dry (24); node-loop hand-over (24)
@@ -238,6 +242,12 @@ int rt_copy_accum_to_device(rt_ctx* ctx, void* dst_device_ptr, size_t n_floats);
 int rt_read_display(rt_ctx* ctx, uint32_t* rgba8, size_t n_pixels);
 
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/* Diagnostics: the acceleration structure the library built behind the reference's flat chunk list (the reference has none:
+ * RayTracing.shader:276-294 loops over all chunks) — n_nodes = rt_stats.numBvhNodes records of 128 bytes each, in the f32
+ * form (six plane arrays of 4 floats, child[4], meta[4]) and in the f16 form the kernels traverse (csrc/bvh.hpp Node4h).
+ * Either destination may be NULL.  Tests check that every f16 box contains its f32 box.                                 */
+int rt_read_bvh(rt_ctx* ctx, void* nodes_f32, void* nodes_f16, size_t n_nodes);
 
 /* ABI self-description for binding generators / tests. */
 int rt_abi_version(void);

@@ -55,6 +55,7 @@ SYMBOLS = [
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
     "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry", "rt_read_display",
+    "rt_read_bvh",
 ]
 
 _lib = None
@@ -99,6 +100,7 @@ def load_library() -> ctypes.CDLL:
     lib.rt_copy_accum_to_device.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.rt_get_stats.argtypes = [c_void_p, c_void_p]
     lib.rt_read_display.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.rt_read_bvh.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
     lib.rt_abi_version.restype = c_int
     lib.rt_sizeof.argtypes = [c_char_p]
     for n in SYMBOLS:
@@ -245,6 +247,13 @@ class Tracer:
 
     def copy_accum_to_device(self, device_ptr: int, n_floats: int):
         self._check(self._lib.rt_copy_accum_to_device(self._ctx, c_void_p(device_ptr), n_floats), "rt_copy_accum_to_device")
+
+    def read_bvh(self):
+        """(f32 nodes [n, 32] float32 view, f16 nodes [n, 32] uint32) of the built BVH4 (see rt_read_bvh)."""
+        n = self.stats()["numBvhNodes"]
+        f32, f16 = np.zeros((n, 32), np.uint32), np.zeros((n, 32), np.uint32)
+        self._check(self._lib.rt_read_bvh(self._ctx, f32.ctypes.data_as(c_void_p), f16.ctypes.data_as(c_void_p), n), "rt_read_bvh")
+        return f32, f16
 
     def stats(self) -> dict:
         s = np.zeros((), STATS)

@@ -22,6 +22,55 @@ struct alignas(16) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
 
+// Compact form of the same node for the traversal kernels (Node4h, also one 128-byte line), derived from a Node4 on the
+// device (rt_geom.hpp k_compact_nodes).  Measured on MI355X (tools/ubench/vmem_rate.hip): an L1-resident wave load costs the
+// CU's vector-memory path ~16 cycles per *instruction* — dwordx2 and dwordx4 alike, 64 active lanes or 16 — and a node
+// visit of the f32 form needs seven of them; adding two more per visit costs the tracer 12 % (profiles/ab_probe_r02.txt).
+// Node4h needs five:
+//   bytes   0.. 63  four (x, y) plane sets of 16 B = 4 x-planes + 4 y-planes as f16 offsets from the node's origin:
+//                   set c = (dir.x < 0) + 2 (dir.y < 0) holds the NEAR planes of a ray with those signs
+//                   (x: min or max per bit 0, y: per bit 1); the FAR planes of that ray are set 3 - c
+//   bytes  64.. 95  (minz[4], maxz[4]) then (maxz[4], minz[4]) as f16: near z then far z for dir.z >= 0 / < 0
+//   bytes  96..111  child[4]
+//   bytes 112..127  origin.xyz (f32), unused
+// plane = origin + offset; every min offset is rounded towards -inf and every max offset towards +inf from the padded f32
+// box, so the compact box contains the f32 one (the hierarchy only prunes; the closest hit is unchanged).  Offsets too
+// large for f16 become +-inf, which keeps the box conservative.  No f16 denormal is ever stored.
+struct alignas(16) Node4h { uint32_t w[32]; };
+static_assert(sizeof(Node4h) == 128, "Node4h must be one 128-byte line");
+
+#if defined(__HIP__)
+#define RTBVH_HD __host__ __device__
+#else
+#define RTBVH_HD
+#endif
+// largest f16 (as bits; no denormals besides zero) that is <= x.  +-inf map to themselves, NaN to +inf / -inf (the widest box).
+RTBVH_HD inline uint16_t f16_round_down(float x)
+{
+    uint32_t u; __builtin_memcpy(&u, &x, 4);
+    const uint32_t sign = u >> 31, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return a > 0x7F800000u ? (uint16_t)0xFC00u : (uint16_t)((sign << 15) | 0x7C00u);   // NaN -> -inf (a lower bound of anything)
+    const bool away = sign != 0;                                   // negative values round away from zero
+    uint32_t h;
+    if (a >= 0x47800000u) h = away ? 0x7C00u : 0x7BFFu;            // |x| >= 65536
+    else if (a < 0x38800000u) h = (away && a != 0) ? 0x0400u : 0u; // |x| < 2^-14: zero, or the smallest normal
+    else {
+        h = (((a >> 23) - 112u) << 10) | ((a >> 13) & 0x3FFu);
+        if (away && (a & 0x1FFFu)) ++h;                            // may carry up to 0x7C00 = inf: |x| > 65504
+    }
+    return (uint16_t)((sign << 15) | h);
+}
+RTBVH_HD inline uint16_t f16_round_up(float x) { return (uint16_t)(f16_round_down(-x) ^ 0x8000u); }
+// the next float32 below / above x (x finite): covers the rounding of the subtraction plane - origin
+RTBVH_HD inline float f32_below(float x)
+{
+    uint32_t u; __builtin_memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return x;
+    if ((u & 0x7FFFFFFFu) == 0u) u = 0x80000001u; else u = (u >> 31) ? u + 1u : u - 1u;
+    __builtin_memcpy(&x, &u, 4); return x;
+}
+RTBVH_HD inline float f32_above(float x) { return -f32_below(-x); }
+
 constexpr uint32_t kEmpty   = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr int      kMaxLeaf = 4;

@@ -71,7 +71,7 @@ struct rt_ctx {
     DevBuf<rtg::MeshXf> d_xf;
     hipEvent_t evg0 = nullptr, evg1 = nullptr;
 
-    DevBuf<float4> d_sph_geom, d_sph_mat, d_nodes, d_tri_geo, d_tri_nrm, d_chunk_mat, d_chunk_box;
+    DevBuf<float4> d_sph_geom, d_sph_mat, d_nodes, d_nodes_h, d_tri_geo, d_tri_nrm, d_chunk_mat, d_chunk_box;
     DevBuf<float>  d_raw_tris;
     DevBuf<uint32_t> d_raw_range;
     DevBuf<float4> d_frame, d_accum;
@@ -90,8 +90,10 @@ struct rt_ctx {
     int auto_choice = -1; double auto_ms[2] = { -1.0, -1.0 };
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
-    int opt_tiles_per_fetch = 2;    // k_stream: measured best (1: 10.24, 2: 10.42, 3: 10.29, 4: 10.06, 8: 9.20 Grays/s)
-    int opt_stream_tile = 2;        // k_stream: log2 of the frames interleaved in a wave (0: 8x8 pixels x 1 frame, 2: 4x4 x 4, 4: 2x2 x 16)
+    int opt_tiles_per_fetch = 4;    // k_stream: measured best with 2x2 x 16 items (2: 11.89, 3: 12.03, 4: 12.17, 5: 12.04, 8: 11.65 Grays/s)
+    int opt_compact_nodes = 1;      // k_trace / k_stream: traverse the f16 form of the nodes (Node4h: 5 loads per visit instead of 7)
+    int opt_stream_tile = 4;        // k_stream: log2 of the most frames interleaved in a wave (0: 8x8 pixels x 1 frame, 2: 4x4 x 4, 4: 2x2 x 16)
+                                    // measured on the 100k-triangle workload: 10.86 / 11.48 / 11.89 Grays/s; with 4 tiles per fetch 12.17
     int opt_node_min = 6;           // k_stream: measured best 4..8 on the 100k-triangle workload (+7 % over 1)
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 0;          // 1: sort all four children; 0: nearest first only (measured +1 %)
@@ -142,6 +144,19 @@ float camera_magnitude(const rt_params& p)
     for (int a = 0; a < 3; ++a)
         axis = std::max(axis, std::fabs(p.camLocalToWorld[4 * a]) + std::fabs(p.camLocalToWorld[4 * a + 1]));
     return m + jitter * axis;
+}
+
+// Node4 -> Node4h on the device (after a build's upload and after every refit)
+int compact_nodes(rt_ctx* c)
+{
+    const uint32_t nn = (uint32_t)c->bvh.nodes.size();
+    RT_HIP(c, c->d_nodes_h.ensure((size_t)nn * 8));
+    if (nn) {
+        hipLaunchKernelGGL(rtg::k_compact_nodes, dim3((nn + 255) / 256), dim3(256), 0, c->stream,
+                           reinterpret_cast<const rtbvh::Node4*>(c->d_nodes.p), reinterpret_cast<rtbvh::Node4h*>(c->d_nodes_h.p), nn);
+        RT_HIP(c, hipGetLastError());
+    }
+    return 0;
 }
 
 // Re-layout of the uploaded buffers + BVH build.  Edge vectors and their cross product are the operands of
@@ -214,6 +229,7 @@ int build_scene(rt_ctx* c)
     if (!c->bvh.nodes.empty())
         RT_HIP(c, hipMemcpyAsync(c->d_nodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node4),
                                  hipMemcpyHostToDevice, c->stream));
+    { int r = compact_nodes(c); if (r) return r; }
     RT_HIP(c, c->d_raw_tris.ensure(nt * 18));
     if (nt) RT_HIP(c, hipMemcpyAsync(c->d_raw_tris.p, c->h_tris.data(), nt * sizeof(rt_triangle), hipMemcpyHostToDevice, c->stream));
 #undef RT_UP
@@ -288,6 +304,7 @@ int run_geometry_kernels(rt_ctx* c, bool have_bvh)
                 hipLaunchKernelGGL(rtg::k_refit_level, dim3(((n1 - n0) * 4 + 255) / 256), dim3(256), 0, c->stream,
                                    reinterpret_cast<rtbvh::Node4*>(c->d_nodes.p), n0, n1, c->d_raw_tris.p, c->d_order.p, G);
         }
+        { int r = compact_nodes(c); if (r) return r; }
     }
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipEventRecord(c->evg1, c->stream));
@@ -331,6 +348,7 @@ int build_scene_local(rt_ctx* c)
     if (!c->bvh.nodes.empty()) {
         RT_HIP(c, hipMemcpyAsync(c->d_nodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node4), hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync(c->d_order.p, c->bvh.order.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        { int r = compact_nodes(c); if (r) return r; }
         hipLaunchKernelGGL(rtg::k_relayout, dim3(((uint32_t)nt + 255) / 256), dim3(256), 0, c->stream,
                            c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_geo.p, c->d_tri_nrm.p, (uint32_t)nt);
         RT_HIP(c, hipGetLastError());
@@ -368,6 +386,16 @@ int ensure_targets(rt_ctx* c)
 
 enum class Variant { Fast, Counting, Flat };
 
+// f(std::bool_constant<a>, std::bool_constant<b>, std::bool_constant<c>) for run-time a, b, c
+template <class Fn> const void* dispatch3(bool a, bool b, bool c3, Fn f)
+{
+    auto lvl2 = [&](auto A) {
+        auto lvl3 = [&](auto B) { return c3 ? f(A, B, std::true_type{}) : f(A, B, std::false_type{}); };
+        return b ? lvl3(std::true_type{}) : lvl3(std::false_type{});
+    };
+    return a ? lvl2(std::true_type{}) : lvl2(std::false_type{});
+}
+
 // One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream, 2 k_pool, 3 k_wave).
 int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int kernel)
 {
@@ -386,7 +414,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (c->target_pixels == 0 || n_frames == 0) return 0;
 
     rtk::DeviceScene S{};
-    S.sph_geom = c->d_sph_geom.p; S.sph_mat = c->d_sph_mat.p; S.nodes = c->d_nodes.p;
+    S.sph_geom = c->d_sph_geom.p; S.sph_mat = c->d_sph_mat.p; S.nodes = c->d_nodes.p; S.nodes_h = c->d_nodes_h.p;
     S.tri_geo = c->d_tri_geo.p; S.tri_nrm = c->d_tri_nrm.p; S.chunk_mat = c->d_chunk_mat.p; S.chunk_box = c->d_chunk_box.p;
     S.raw_tris = c->d_raw_tris.p; S.raw_chunk_range = c->d_raw_range.p;
     S.ns = (int)c->h_spheres.size(); S.nn = (int)c->bvh.nodes.size();
@@ -430,13 +458,13 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
                      : waved ? rtk::wv::wave_lds_bytes(F.stack_cap) * rtk::kWavesPerBlock
                               : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
     if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
+    const bool counting = var == Variant::Counting;
+    const bool compact = c->opt_compact_nodes != 0;            // k_trace / k_stream only; k_pool, k_wave and the flat twin read the f32 nodes
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
-                   : pooled ? (var == Variant::Fast ? (const void*)rtk::k_pool<false> : (const void*)rtk::k_pool<true>)
-                   : waved ? (var == Variant::Fast ? (const void*)rtk::k_wave<false> : (const void*)rtk::k_wave<true>)
-                   : stream ? (philox ? (var == Variant::Fast ? (const void*)rtk::k_stream<false, true> : (const void*)rtk::k_stream<true, true>)
-                                     : (var == Variant::Fast ? (const void*)rtk::k_stream<false> : (const void*)rtk::k_stream<true>))
-                   : philox ? (var == Variant::Fast ? (const void*)rtk::k_trace<false, false, true> : (const void*)rtk::k_trace<true, false, true>)
-                            : (var == Variant::Fast ? (const void*)rtk::k_trace<false, false> : (const void*)rtk::k_trace<true, false>);
+                   : pooled ? (counting ? (const void*)rtk::k_pool<true> : (const void*)rtk::k_pool<false>)
+                   : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
+                   : stream ? dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_stream<decltype(C)::value, decltype(P)::value, decltype(H)::value>; })
+                            : dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, decltype(H)::value>; });
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::kBlock, lds));
@@ -515,34 +543,20 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         // k_stream, frame-interleaved sub-tiles: a wave = (4x4 or 2x2 pixels) x (4 or 16 frames); launches take whole frame
         // groups, the remainder of the render goes out as 8x8 x 1 items
         A.fg_log2 = 0;
-        if (stream_tiles && c->opt_stream_tile > 0 && nb >= (1 << c->opt_stream_tile)) {
-            nb -= nb % (1 << c->opt_stream_tile);
-            A.fg_log2 = c->opt_stream_tile;
+        if (stream_tiles) {
+            int fg = c->opt_stream_tile;
+            while (fg > 0 && nb < (1 << fg)) fg -= 2;            // the largest group the rest of the render fills
+            nb -= nb % (1 << fg);
+            A.fg_log2 = fg;
         }
         F.frame = first_frame + i;
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
         F.out_frame = nb > 1 ? c->d_batch.p : c->d_frame.p;
         RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
         WA.total_pixels = (unsigned int)ntiles * 64u * (unsigned int)nb;
-        if (var == Variant::Flat) hipLaunchKernelGGL((rtk::k_trace<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
-        else if (waved) {
-            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_wave<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, WA);
-            else                      hipLaunchKernelGGL((rtk::k_wave<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, WA);
-        } else if (pooled) {
-            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_pool<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
-            else                      hipLaunchKernelGGL((rtk::k_pool<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, PA);
-        } else if (stream) {
-            if (philox) {
-                if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
-                else                      hipLaunchKernelGGL((rtk::k_stream<true, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
-            } else if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_stream<false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
-            else                             hipLaunchKernelGGL((rtk::k_stream<true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F, A);
-        } else if (philox) {
-            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_trace<false, false, true>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
-            else                      hipLaunchKernelGGL((rtk::k_trace<true, false, true>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
-        } else {
-            if (var == Variant::Fast) hipLaunchKernelGGL((rtk::k_trace<false, false>), dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
-            else                      hipLaunchKernelGGL((rtk::k_trace<true, false>),  dim3(grid), dim3(rtk::kBlock), lds, c->stream, S, F);
+        {
+            void* args[3] = { (void*)&S, (void*)&F, waved ? (void*)&WA : pooled ? (void*)&PA : (void*)&A };    // k_trace takes (S, F) only
+            RT_HIP(c, hipLaunchKernel(fn, dim3(grid), dim3(rtk::kBlock), args, lds, c->stream));
         }
         RT_HIP(c, hipGetLastError());
         if (nb > 1) {
@@ -717,7 +731,7 @@ void rt_destroy(rt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
+    c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
     c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
@@ -857,6 +871,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "tiles_per_fetch")) { if (value < 1 || value > 16) return fail(c, -2, "tiles_per_fetch must be in [1,16]"); c->opt_tiles_per_fetch = value; }
     else if (!std::strcmp(name, "node_min")) { if (value < 1 || value > 64) return fail(c, -2, "node_min must be in [1,64]"); c->opt_node_min = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
+    else if (!std::strcmp(name, "compact_nodes")) c->opt_compact_nodes = value ? 1 : 0;
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }
@@ -921,6 +936,19 @@ int rt_read_display(rt_ctx* c, uint32_t* rgba8, size_t n_pixels)
     float ms = 0.f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
     c->stats.lastDisplayMs = ms;
+    return 0;
+}
+
+int rt_read_bvh(rt_ctx* c, void* nodes_f32, void* nodes_f16, size_t n_nodes)
+{
+    if (!c) return -1;
+    if (c->scene_dirty) return fail(c, -2, "the scene has not been built yet (render a frame first)");
+    if (n_nodes != c->bvh.nodes.size()) return fail(c, -2, "expected %zu nodes, got %zu", c->bvh.nodes.size(), n_nodes);
+    if (!n_nodes) return 0;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (nodes_f32) RT_HIP(c, hipMemcpy(nodes_f32, c->d_nodes.p, n_nodes * 128, hipMemcpyDeviceToHost));
+    if (nodes_f16) RT_HIP(c, hipMemcpy(nodes_f16, c->d_nodes_h.p, n_nodes * 128, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -136,6 +136,44 @@ __global__ __launch_bounds__(256) void k_refit_level(rtbvh::Node4* __restrict__ 
     N.maxx[k] = mx[0]; N.maxy[k] = mx[1]; N.maxz[k] = mx[2];
 }
 
+// Node4 -> Node4h (bvh.hpp): one thread per node, 128 B in, 128 B out.  Runs after the host build's upload and after every refit.
+__global__ __launch_bounds__(256) void k_compact_nodes(const rtbvh::Node4* __restrict__ nodes, rtbvh::Node4h* __restrict__ out, uint32_t nn)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    const rtbvh::Node4 N = nodes[i];
+    const float* mins[3] = { N.minx, N.miny, N.minz };
+    const float* maxs[3] = { N.maxx, N.maxy, N.maxz };
+    float O[3];
+    uint16_t hmin[3][4], hmax[3][4];
+    const float INF = __builtin_inff();
+    for (int a = 0; a < 3; ++a) {
+        float lo = INF, hi = -INF;
+        for (int k = 0; k < 4; ++k) {
+            if (mins[a][k] > -INF && mins[a][k] < INF) lo = __builtin_fminf(lo, mins[a][k]);
+            if (maxs[a][k] > -INF && maxs[a][k] < INF) hi = __builtin_fmaxf(hi, maxs[a][k]);
+        }
+        float o = 0.5f * lo + 0.5f * hi;
+        if (!(o > -INF && o < INF)) o = (lo < INF) ? lo : (hi > -INF ? hi : 0.0f);
+        O[a] = o;
+        for (int k = 0; k < 4; ++k) {
+            hmin[a][k] = rtbvh::f16_round_down(rtbvh::f32_below(mins[a][k] - o));
+            hmax[a][k] = rtbvh::f16_round_up(rtbvh::f32_above(maxs[a][k] - o));
+        }
+    }
+    rtbvh::Node4h H;
+    auto pack4 = [](const uint16_t* h, uint32_t* w) { w[0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16); w[1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16); };
+    for (int c = 0; c < 4; ++c) {
+        pack4((c & 1) ? hmax[0] : hmin[0], &H.w[4 * c]);
+        pack4((c & 2) ? hmax[1] : hmin[1], &H.w[4 * c + 2]);
+    }
+    pack4(hmin[2], &H.w[16]); pack4(hmax[2], &H.w[18]);
+    pack4(hmax[2], &H.w[20]); pack4(hmin[2], &H.w[22]);
+    for (int k = 0; k < 4; ++k) H.w[24 + k] = N.child[k];
+    H.w[28] = __float_as_uint(O[0]); H.w[29] = __float_as_uint(O[1]); H.w[30] = __float_as_uint(O[2]); H.w[31] = 0u;
+    out[i] = H;
+}
+
 // ---- display step after the path: linear RGBA32F -> sRGB RGBA8 (the reference's final Blit(resultTexture, target) into an
 // sRGB back buffer, RayTracingManager.cs:84, ProjectSettings.asset:50).  16 B read + 4 B write per pixel.
 __device__ __forceinline__ float linear_to_srgb(float c)

@@ -29,6 +29,7 @@ struct DeviceScene {
     const float4* sph_geom;     // [ns]      (centre.xyz, radius)                         16 B
     const float4* sph_mat;      // [ns*4]    rt_material as 4 float4                      64 B
     const float4* nodes;        // [nn*8]    rtbvh::Node4                                128 B
+    const float4* nodes_h;      // [nn*8]    rtbvh::Node4h (f16 planes around a per-node origin: 5 loads per visit instead of 7)
     const float4* tri_geo;      // [nt*3]    BVH order: (A, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz) 48 B
     const float4* tri_nrm;      // [nt*3]    BVH order: (nA, chunk) (nB, orig index) (nC, -)   48 B
     const float4* chunk_mat;    // [nm*4]    rt_material of the chunk                     64 B
@@ -174,41 +175,87 @@ __device__ __forceinline__ bool ray_triangle(v3 o, v3 d, v3 A, v3 eAB, v3 eAC, v
 // hierarchy only prunes, so its arithmetic is free to differ from the reference's (boxes are padded for it:
 // bvh.cpp pad_box).  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma/v_mul/v_add issue at ~2.5 cycles
 // per wave, v_min/v_max/v_cmp/v_cndmask at ~4.2 — so the slab test avoids per-axis min/max altogether.
-struct RaySlab {
+template <bool H> struct RaySlabT;
+template <> struct RaySlabT<false> {
     v3 inv;             // 1 / d  (RayBoundingBox :179 — also used by the literal chunk filter)
     v3 oinv;            // o * inv
     uint32_t nx, ny, nz;   // byte offsets of the near-plane float4s (x: 0|48, y: 16|64, z: 32|80)
     uint32_t fx, fy, fz;   // ... and of the far-plane ones (the other of each pair)
 };
+// Node4h (bvh.hpp): the ray's signs pick one of four 16-B (x, y) plane sets as its near planes, the complementary set as its
+// far planes, and one of two 16-B (near z, far z) sets
+template <> struct RaySlabT<true> {
+    v3 inv, oinv;
+    uint32_t nxy, fxy, zo; // byte offsets inside the node: near (x,y) set, far (x,y) set, z set
+};
+using RaySlab = RaySlabT<false>;
 
-__device__ __forceinline__ RaySlab make_slab(v3 o, v3 d)
+template <bool H = false>
+__device__ __forceinline__ RaySlabT<H> make_slab(v3 o, v3 d)
 {
-    RaySlab r;
+    RaySlabT<H> r;
     r.inv = rtm::mk(rtm::rcp_(d.x), rtm::rcp_(d.y), rtm::rcp_(d.z));
     r.oinv = rtm::mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
-    r.nx = d.x < 0.0f ? 48u : 0u;
-    r.ny = d.y < 0.0f ? 64u : 16u;
-    r.nz = d.z < 0.0f ? 80u : 32u;
-    r.fx = 48u - r.nx; r.fy = 80u - r.ny; r.fz = 112u - r.nz;
+    if constexpr (H) {
+        r.nxy = (d.x < 0.0f ? 16u : 0u) + (d.y < 0.0f ? 32u : 0u);
+        r.fxy = 48u - r.nxy;
+        r.zo = d.z < 0.0f ? 80u : 64u;
+    } else {
+        r.nx = d.x < 0.0f ? 48u : 0u;
+        r.ny = d.y < 0.0f ? 64u : 16u;
+        r.nz = d.z < 0.0f ? 80u : 32u;
+        r.fx = 48u - r.nx; r.fy = 80u - r.ny; r.fz = 112u - r.nz;
+    }
     return r;
 }
 
 // Tests the four child boxes of node `cur`, returns them sorted by entry distance (t0 <= t1 <= t2 <= t3, misses
 // carry t = +inf).  Empty slots hold (+inf, -inf) boxes and can never be hit.
-__device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint32_t cur, const RaySlab& r, float best_t, bool full_sort,
+typedef _Float16 rt_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rt_half2 as_half2(uint32_t u) { return __builtin_bit_cast(rt_half2, u); }
+
+template <bool H>
+__device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint32_t cur, const RaySlabT<H>& r, float best_t, bool full_sort,
                                           float& t0, float& t1, float& t2, float& t3,
                                           uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3)
 {
-    // 32-bit byte offsets from the (wave-uniform) node array: one shift and six adds per node instead of 64-bit address
+    // 32-bit byte offsets from the (wave-uniform) node array: one shift and a few adds per node instead of 64-bit address
     // arithmetic per load (the host refuses BVHs of 2^25 nodes or more)
     const char* nb = reinterpret_cast<const char*>(nodes);
     const uint32_t base = cur << 7;
+    const float INF = __builtin_inff();
+    if constexpr (H) {
+        const uint4 na = *reinterpret_cast<const uint4*>(nb + (base + r.nxy)), fa = *reinterpret_cast<const uint4*>(nb + (base + r.fxy));
+        const uint4 zz = *reinterpret_cast<const uint4*>(nb + (base + r.zo));
+        const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
+        const float4 og = *reinterpret_cast<const float4*>(nb + (base + 112u));
+        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+        // t = (origin + offset) * inv - o*inv = offset * inv + (origin * inv - o*inv): one f32 FMA per axis and node, then one
+        // v_fma_mix_f32 (f16 offset x f32 + f32) per plane
+        const float kx = __builtin_fmaf(og.x, r.inv.x, -r.oinv.x), ky = __builtin_fmaf(og.y, r.inv.y, -r.oinv.y), kz = __builtin_fmaf(og.z, r.inv.z, -r.oinv.z);
+#define RT_SLABH(XW, YW, ZNW, ZFW, E, TK)                                                                                 \
+        {                                                                                                                \
+            const float nx_ = __builtin_fmaf((float)as_half2(na.XW).E, r.inv.x, kx), fx_ = __builtin_fmaf((float)as_half2(fa.XW).E, r.inv.x, kx); \
+            const float ny_ = __builtin_fmaf((float)as_half2(na.YW).E, r.inv.y, ky), fy_ = __builtin_fmaf((float)as_half2(fa.YW).E, r.inv.y, ky); \
+            const float nz_ = __builtin_fmaf((float)as_half2(zz.ZNW).E, r.inv.z, kz), fz_ = __builtin_fmaf((float)as_half2(zz.ZFW).E, r.inv.z, kz); \
+            const float tn_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx_, ny_), nz_), 0.0f);                    \
+            const float tf_ = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx_, fy_), fz_), best_t);                  \
+            TK = (tn_ <= tf_) ? tn_ : INF;                                                                               \
+        }
+        RT_SLABH(x, z, x, z, x, t0) RT_SLABH(x, z, x, z, y, t1) RT_SLABH(y, w, y, w, x, t2) RT_SLABH(y, w, y, w, y, t3)
+#undef RT_SLABH
+    } else {
     const float4 px = *reinterpret_cast<const float4*>(nb + (base + r.nx)), qx = *reinterpret_cast<const float4*>(nb + (base + r.fx));
     const float4 py = *reinterpret_cast<const float4*>(nb + (base + r.ny)), qy = *reinterpret_cast<const float4*>(nb + (base + r.fy));
     const float4 pz = *reinterpret_cast<const float4*>(nb + (base + r.nz)), qz = *reinterpret_cast<const float4*>(nb + (base + r.fz));
     const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
     c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
-    const float INF = __builtin_inff();
+#ifdef RT_PROBE_LOADS       // sensitivity probe (never in the product build): RT_PROBE_LOADS extra dwordx4 loads per node step
+    for (int k_ = 0; k_ < RT_PROBE_LOADS; ++k_) { float4 pv_; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pv_) : "v"(base + 112u), "s"(nb)); }
+#endif
+#ifdef RT_PROBE_VALU        // ... or RT_PROBE_VALU extra full-rate VALU instructions
+    { float pa_ = r.inv.x; for (int k_ = 0; k_ < RT_PROBE_VALU; ++k_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pa_)); }
+#endif
 #define RT_SLAB(K, TK)                                                                                                   \
     {                                                                                                                    \
         const float nx_ = __builtin_fmaf(px.K, r.inv.x, -r.oinv.x), fx_ = __builtin_fmaf(qx.K, r.inv.x, -r.oinv.x);      \
@@ -220,6 +267,7 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
     }
     RT_SLAB(x, t0) RT_SLAB(y, t1) RT_SLAB(z, t2) RT_SLAB(w, t3)
 #undef RT_SLAB
+    }
 #define RT_CSWAP(TA, CA, TB, CB) { const bool s_ = TB < TA; const float tt_ = s_ ? TB : TA, tu_ = s_ ? TA : TB;         \
                                    const uint32_t ct_ = s_ ? CB : CA, cu_ = s_ ? CA : CB; TA = tt_; TB = tu_; CA = ct_; CB = cu_; }
     // the nearest child must come first; a full sort of the other three (2 more exchanges) only refines the order in
@@ -241,7 +289,7 @@ __device__ __forceinline__ void load_tri(const float4* __restrict__ tri_geo, uin
 }
 
 // ---- closest hit: spheres, then BVH ---------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool H = false>
 __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_mode, bool full_sort, v3 o, v3 d,
                                            const TravStack& stk, Counters& cnt)
 {
@@ -259,7 +307,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
     }
 
     if (S.nn > 0) {
-        const RaySlab slab = make_slab(o, d);
+        const RaySlabT<H> slab = make_slab<H>(o, d);
         const v3 inv = slab.inv;                                        // RayBoundingBox :179
         int sp = 0;
         uint32_t cur = 0;                                               // root
@@ -275,7 +323,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
                 phase_tick<COUNT>(cnt, 0);
                 float t0, t1, t2, t3;
                 uint32_t c0, c1, c2, c3;
-                node_step(S.nodes, cur, slab, best.t, full_sort, t0, t1, t2, t3, c0, c1, c2, c3);
+                node_step<H>(H ? S.nodes_h : S.nodes, cur, slab, best.t, full_sort, t0, t1, t2, t3, c0, c1, c2, c3);
                 const float INF = __builtin_inff();
                 if (t3 < INF) RT_PUSH(c3)
                 if (t2 < INF) RT_PUSH(c2)
@@ -393,7 +441,7 @@ __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, 
 }
 
 // One pixel of one frame: frag :356-389 as a flat state machine (see file header).
-template <bool COUNT, bool FLAT, bool PHILOX>
+template <bool COUNT, bool FLAT, bool PHILOX, bool H = false>
 __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, int frame, int x, int y,
                                            const TravStack& stk, Counters& cnt)
 {
@@ -425,7 +473,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
     while (alive) {
         Hit h; v3 nrm_flat; uint32_t chunk_flat;
         if (FLAT) { h = closest_hit_flat(S, p.intersectMode, o, d, nrm_flat, chunk_flat); cnt.rays++; }
-        else      h = closest_hit<COUNT>(S, p.intersectMode, full_sort, o, d, stk, cnt);
+        else      h = closest_hit<COUNT, H>(S, p.intersectMode, full_sort, o, d, stk, cnt);
 
         bool path_done;
         if (h.id != kNone) {
@@ -509,7 +557,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
 constexpr int kBlock = 256;         // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 
-template <bool COUNT, bool FLAT, bool PHILOX = false>
+template <bool COUNT, bool FLAT, bool PHILOX = false, bool H = false>
 __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, FrameArgs F)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -541,7 +589,7 @@ __global__ __launch_bounds__(kBlock) RT_KTRACE_ATTR void k_trace(DeviceScene S, 
         const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
-            v3 c = render_pixel<COUNT, FLAT, PHILOX>(S, F.p, F.full_sort != 0, F.frame + (int)fi, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT, PHILOX, H>(S, F.p, F.full_sort != 0, F.frame + (int)fi, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[(size_t)fi * F.frame_stride + pi] = make_float4(c.x, c.y, c.z, 1.0f);     // frag :388
             if (!batched) {

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                         phase_tick<COUNT>(cnt, 0);
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
-                        node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
+                        node_step<false>(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
                         if (t3 < INF) push(c3);
                         if (t2 < INF) push(c2);
                         if (t1 < INF) push(c1);

@@ -38,7 +38,7 @@ struct StreamArgs {
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
-template <bool COUNT, bool PHILOX = false>
+template <bool COUNT, bool PHILOX = false, bool H = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if constexpr (PHILOX) rng.init(0u, 0u); else rng = 0u;
     int sample = 0, bounce = 0;
     v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
-    RaySlab slab = make_slab(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
+    RaySlabT<H> slab = make_slab<H>(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
     uint32_t cur = kNone;
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         const bool traceable = o.x == o.x && o.y == o.y && o.z == o.z && a == a
                                                && !(d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
                         if (S.nn > 0 && traceable) {
-                            slab = make_slab(o, d);                                     // RayBoundingBox :179
+                            slab = make_slab<H>(o, d);                                  // RayBoundingBox :179
                             cur = 0; sp = 0; mode = kModeTrav;
                         }
                     }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         phase_tick<COUNT>(cnt, 0);
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
-                        node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
+                        node_step<H>(H ? S.nodes_h : S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
                         if (gstk == nullptr || ballot_(sp + 3 > cap) == 0) {
                             // branch-free push of the three farther children (far -> near); slots past the new top are garbage
                             stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         phase_tick<COUNT>(cnt, 0);
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
-                        node_step(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
+                        node_step<false>(S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
                         // branch-free push of the three farther children (far -> near); slots past the new top are garbage
                         stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
                         stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;

@@ -292,7 +292,7 @@ def test_tile_groups_multi_frame(rtx, oracle, tracer, size, k):
         acc, last = run_gpu(tracer, b, 1, 3, kernel=1)
         st = tracer.stats()
     finally:
-        tracer.set_option("tiles_per_fetch", 2)
+        tracer.set_option("tiles_per_fetch", 4)
     want, want_last, cnt = oracle.render(*b, 1, 3)
     assert_bitwise(last, want_last, f"{size} k={k}: last frame")
     assert_bitwise(acc, want, f"{size} k={k}: accum")
@@ -325,10 +325,83 @@ def test_frame_interleaved_sub_tiles(rtx, oracle, tracer, stream_tile, size, n, 
             rows = list(range(H))
         st = tracer.stats()
     finally:
-        tracer.set_option("stream_tile", 2)
+        tracer.set_option("stream_tile", 4)
         tracer.set_rows(0, H)
     want, want_last, cnt = oracle.render(*b, 2, n)
     assert_bitwise(last, want_last[rows], f"stream_tile {stream_tile} {size} x{n}: last frame")
     assert_bitwise(acc, want[rows], f"stream_tile {stream_tile} {size} x{n}: accum")
     if not bands:
         assert st["rays"] == cnt["rays"]
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_f32_nodes_and_f16_nodes_give_the_same_image(rtx, oracle, tracer, mode, kernel):
+    """compact_nodes = 0 (seven f32 plane loads per node visit) against the default f16 form: both equal the oracle."""
+    b = rtx.scenes.mesh_test_scene(96, 64).build_buffers()
+    want, want_last, cnt = oracle.render(*b, 1, 4, mode=mode)
+    for compact in (0, 1):
+        tracer.set_option("compact_nodes", compact)
+        try:
+            acc, last = run_gpu(tracer, b, 1, 4, mode=mode, kernel=kernel)
+            st = tracer.stats()
+        finally:
+            tracer.set_option("compact_nodes", 1)
+        assert_bitwise(last, want_last, f"compact_nodes={compact} kernel {kernel} mode {mode}: last frame")
+        assert_bitwise(acc, want, f"compact_nodes={compact} kernel {kernel} mode {mode}: accum")
+        assert st["rays"] == cnt["rays"]
+
+
+def _decode_f16_nodes(h):
+    """Node4h words [n, 32] -> (mins [n, 3, 4], maxs [n, 3, 4]) as float64 = origin + offset, checking that the plane sets agree."""
+    n = h.shape[0]
+    halves = h[:, :24].copy().view(np.float16).astype(np.float64).reshape(n, 6, 8)          # six 16-byte sets of 8 halves
+    org = h[:, 28:31].copy().view(np.float32).astype(np.float64)                             # [n, 3]
+    sets = halves[:, :4].reshape(n, 4, 2, 4)                                                 # set c: (x planes, y planes)
+    minx, maxx, miny, maxy = sets[:, 0, 0], sets[:, 1, 0], sets[:, 0, 1], sets[:, 2, 1]
+    assert np.array_equal(sets[:, 2, 0], minx) and np.array_equal(sets[:, 3, 0], maxx)       # bit 0 of c picks the x planes
+    assert np.array_equal(sets[:, 1, 1], miny) and np.array_equal(sets[:, 3, 1], maxy)       # bit 1 the y planes
+    minz, maxz = halves[:, 4, :4], halves[:, 4, 4:]
+    assert np.array_equal(halves[:, 5, :4], maxz) and np.array_equal(halves[:, 5, 4:], minz)
+    mins = np.stack([minx, miny, minz], 1) + org[:, :, None]
+    maxs = np.stack([maxx, maxy, maxz], 1) + org[:, :, None]
+    return mins, maxs
+
+
+@pytest.mark.parametrize("scene", ["mesh_test", "config3", "far"])
+def test_f16_boxes_contain_the_f32_boxes(rtx, tracer, scene):
+    """Every child box of the f16 node form contains the padded f32 box it was derived from (so the hierarchy still only
+    prunes), is at most ~0.1 % of the node's extent wider, holds no f16 denormal, and keeps the child references."""
+    if scene == "config3":
+        b = rtx.scenes.config3(64, 36).build_buffers()
+    else:
+        b = rtx.scenes.mesh_test_scene(32, 24).build_buffers()
+        if scene == "far":                       # the whole scene 1e5 units from the origin: offsets stay small, the origin carries it
+            params, spheres, tris, infos = (a.copy() for a in b)
+            off = np.float32([1.0e5, -3.0e4, 7.0e4])
+            for k in ("posA", "posB", "posC"):
+                tris[k] += off
+            infos["boundsMin"] += off; infos["boundsMax"] += off
+            params["worldSpaceCameraPos"] += off
+            m = params["camLocalToWorld"].reshape(4, 4); m[:3, 3] += off
+            b = (params, spheres, tris, infos)
+    run_gpu(tracer, b, 0, 1, kernel=1)
+    f32, f16 = tracer.read_bvh()
+    assert len(f32) > 0
+    planes = f32[:, :24].copy().view(np.float32).astype(np.float64).reshape(-1, 6, 4)
+    mins32, maxs32 = planes[:, :3], planes[:, 3:]
+    assert np.array_equal(f16[:, 24:28], f32[:, 24:28])
+    mins16, maxs16 = _decode_f16_nodes(f16)
+    used = f32[:, 24:28] != 0xFFFFFFFF
+    u3 = np.broadcast_to(used[:, None, :], mins32.shape)
+    assert (mins16[u3] <= mins32[u3]).all() and (maxs16[u3] >= maxs32[u3]).all()
+    # empty slots stay un-enterable: min = +inf, max = -inf
+    assert np.isposinf(mins16[~u3]).all() and np.isneginf(maxs16[~u3]).all()
+    # tightness: the widening is bounded by the f16 step at the offset's magnitude (<= 2^-10 of the node's half extent, plus the
+    # smallest normal 2^-14)
+    lo = np.where(u3, mins32, np.inf).min(axis=2, keepdims=True); hi = np.where(u3, maxs32, -np.inf).max(axis=2, keepdims=True)
+    slack = (hi - lo) * 0.5 * 2.0 ** -9 + 2.0 ** -13
+    assert ((mins32 - mins16)[u3] <= np.broadcast_to(slack, mins32.shape)[u3]).all()
+    assert ((maxs16 - maxs32)[u3] <= np.broadcast_to(slack, mins32.shape)[u3]).all()
+    halves = f16[:, :24].copy().view(np.uint16)
+    assert not (((halves & 0x7C00) == 0) & ((halves & 0x03FF) != 0)).any(), "an f16 denormal was stored"
