@@ -26,9 +26,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-L1_PEAK_GBPS = 256 * 64 * 2.4          # 256 CUs x 64 B/clk x 2.4 GHz = 39.3 TB/s of vector L1 bandwidth
 PEAK_HBM_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-NODE_BYTES, TRI_BYTES, SPHERE_BYTES, HIT_BYTES, PIXEL_BYTES = 128, 48, 16, 64 + 48, 48
+PEAK_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak = 256 CUs x 4 SIMDs x 1 wave64 FMA per 2 cycles x 2.4 GHz
+PEAK_VALU_WAVE_INSTR = 256 * 4 * 2.4e9 / 2       # wave-instructions per second at that rate
+# algorithmic bytes per ray = nodes x 32 + triangles x 48 + spheres x 16 + (hit ? 64 + 48 : 0); per pixel and frame 48.
+# The survey's 32 B assumed a binary node; the BVH4 node this build visits is loaded as 5 x 16 B (f16 form) or 7 x 16 B (f32 form).
+NODE_BYTES_SURVEY, NODE_BYTES_F16, NODE_BYTES_F32 = 32, 80, 112
+TRI_BYTES, SPHERE_BYTES, HIT_BYTES, PIXEL_BYTES = 48, 16, 64 + 48, 48
+VMEM_CYCLES_PER_WAVE_LOAD = 16.2     # tools/ubench/vmem_rate.hip (profiles/ubench_r02_vmem_rate.txt): L1-resident dwordx2/x4, per CU
 
 
 def parse():
@@ -50,6 +55,7 @@ def parse():
     ap.add_argument("--rng", choices=["pcg", "philox"], default="pcg", help="pcg = the reference's stream (parity mode, headline); philox = counter-based mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
+    ap.add_argument("--no-latency", action="store_true", help="skip the (untimed) single-frame latency measurements")
     return ap.parse_args()
 
 
@@ -209,35 +215,52 @@ def main():
 
     # ---- roofline (rank 0's strip): counting build of the same kernel over the same K frames, untimed
     roofline = None
+    kernel_names = ({1: "k_stream<false,true,{H}>"} if args.rng == "philox" else
+                    {0: "k_trace<false,false,false,{H}>", 1: "k_stream<false,false,{H}>", 2: "k_pool<false>", 3: "k_wave<false>"})
+    chosen = st.get("autoKernel", -1) if args.kernel < 0 else args.kernel
+    opts = dict(kv.split("=") for kv in args.opt)
+    compact = int(opts.get("compact_nodes", 1)) != 0
+    kernel_name = kernel_names.get(chosen, "k_trace<false,false,true,{H}>" if args.rng == "philox" else "k_trace<false,false,false,{H}>").replace(
+        "{H}", "true" if compact else "false")
     if not args.no_roofline:
         tr.reset_accum()
         tr.render_counting(0, args.steps)
         sc = tr.stats()
         px = nrows * W * args.steps
-        alg = (sc["nodeVisits"] * NODE_BYTES + sc["triTests"] * TRI_BYTES + sc["sphereTests"] * SPHERE_BYTES
-               + sc["hits"] * HIT_BYTES + px * PIXEL_BYTES)
-        fpl = max(1, int(st.get("lastFramesPerLaunch", 1)))           # frames traced per k_trace launch in the timed region
+        fpl = max(1, int(st.get("lastFramesPerLaunch", 1)))           # frames traced per launch in the timed region
         launches = (args.steps + fpl - 1) // fpl if args.steps else 1
-        per_launch = alg / max(launches, 1)
         launch_s = kernel_ms_rank0 / 1e3 / max(launches, 1)
-        ach = per_launch / launch_s / 1e9
-        traffic, pmc_extra = None, None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
+
+        def alg_bytes(node_bytes):
+            return (sc["nodeVisits"] * node_bytes + sc["triTests"] * TRI_BYTES + sc["sphereTests"] * SPHERE_BYTES
+                    + sc["hits"] * HIT_BYTES + px * PIXEL_BYTES) / max(launches, 1)
+        loaded = alg_bytes(NODE_BYTES_F16 if compact else NODE_BYTES_F32)
+        # PMC figures of the same workload and kernel (rocprofv3 --pmc passes, profiles/pmc_table.json), stored per frame so that
+        # any --steps scales them; only for the N = 1 launch they were measured on
+        pmc, traffic = None, None
+        tf = os.path.join(ROOT, "profiles", "pmc_table.json")
+        if os.path.exists(tf) and world == 1 and args.rng == "pcg":
             try:
-                tj = json.load(open(tf))
-                key = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}_x{fpl}"
-                traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None   # measured for the N=1 launch
-                pmc_extra = {k: tj.get(key, {}).get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_active_frac_per_simd", "ta_busy_frac", "td_busy_frac", "valu_lane_utilisation")} if world == 1 else None
+                ent = json.load(open(tf)).get(f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}")
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBPS, 5), "traffic": traffic,
-                    "kernel": ({1: "k_stream<false,true>"} if args.rng == "philox" else
-                               {0: "k_trace<false,false,false>", 1: "k_stream<false>", 2: "k_pool<false>", 3: "k_wave<false>"}).get(
-                                  st.get("autoKernel", -1) if args.kernel < 0 else args.kernel,
-                                  "k_trace<false,false,true>" if args.rng == "philox" else "k_trace<false,false,false>"), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl, "launches": launches,
-                    "algorithmic_bytes_per_launch": int(per_launch),
+                ent = None
+            if ent and ent.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
+                pmc = ent
+                traffic = int(ent["hbm_bytes_per_frame"] * fpl)
+        hbm = {"peak": PEAK_HBM_GBPS, "unit": "GB/s",
+               "algorithmic_survey_32B_nodes": round(alg_bytes(NODE_BYTES_SURVEY) / launch_s / 1e9, 1),
+               "algorithmic_bytes_loaded": round(loaded / launch_s / 1e9, 1),
+               "note": "algorithmic bytes are served by L1/L2/Infinity Cache (hit rates in pmc); `measured` is what reaches HBM",
+               "measured": round(traffic / launch_s / 1e9, 1) if traffic else None,
+               "measured_frac": round(traffic / launch_s / 1e9 / PEAK_HBM_GBPS, 5) if traffic else None}
+        hbm["algorithmic_survey_frac"] = round(hbm["algorithmic_survey_32B_nodes"] / PEAK_HBM_GBPS, 5)
+        roofline = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_VALU_TFLOPS, "achieved": None, "frac": None,
+                    "traffic": traffic, "kernel": kernel_name, "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl,
+                    "launches": launches, "algorithmic_bytes_per_launch": int(loaded),
+                    "definition": "bound = VALU issue: achieved = VALU wave-instructions/s (SQ_INSTS_VALU per frame from the committed "
+                                  "rocprofv3 pass x frames / launch time measured here) x 64 lanes x 2, against the FP32 vector peak; "
+                                  "the working set is cache-resident, so HBM is not the roof (see hbm)",
+                    "hbm": hbm,
                     "per_ray": {"nodes": round(sc["nodeVisits"] / max(sc["rays"], 1), 2),
                                 "tris": round(sc["triTests"] / max(sc["rays"], 1), 2),
                                 "spheres": round(sc["sphereTests"] / max(sc["rays"], 1), 2)},
@@ -248,13 +271,49 @@ def main():
                     "primitive_tests_per_s": {"box": round(sc["nodeVisits"] * 4 / (kernel_ms_rank0 / 1e3), 0),
                                               "triangle": round(sc["triTests"] / (kernel_ms_rank0 / 1e3), 0),
                                               "sphere": round(sc["sphereTests"] / (kernel_ms_rank0 / 1e3), 0)},
-                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]},
-                    # the working set is cache-resident: what the traversal really loads is the vector L1 -> VGPR path
-                    # (64 B/clk per CU); a wave's load occupies it for all 64 lanes, so the lane-utilisation-corrected figure is given too
-                    "vector_l1": {"achieved": round(ach, 2), "peak": L1_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / L1_PEAK_GBPS, 5),
-                                  "frac_counting_idle_lanes": round(ach / L1_PEAK_GBPS / max(sc["phaseLanes"][0] / max(64 * sc["phaseExecs"][0], 1), 1e-9), 5)
-                                  if sc["phaseExecs"][0] else None},
-                    "limiter": "VALU issue and the vector-memory return path (TD) together; cache-resident working set: see pmc", "pmc": pmc_extra}
+                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]}, "pmc": None}
+        if pmc:
+            instr_s = pmc["valu_wave_instructions_per_frame"] * fpl / launch_s
+            roofline["achieved"] = round(instr_s * 64 * 2 / 1e12, 2)
+            roofline["frac"] = round(instr_s / PEAK_VALU_WAVE_INSTR, 5)
+            lane = pmc.get("valu_lane_utilisation")
+            loads_s = pmc["vmem_read_wave_instructions_per_frame"] * fpl / launch_s
+            roofline["frac_active_lanes"] = round(roofline["frac"] * lane, 5) if lane else None
+            roofline["vector_memory"] = {"wave_loads_per_s": round(loads_s, 0), "cycles_per_wave_load_per_cu": VMEM_CYCLES_PER_WAVE_LOAD,
+                                         "frac": round(loads_s * VMEM_CYCLES_PER_WAVE_LOAD / (256 * 2.4e9), 5)}
+            roofline["pmc"] = {k: pmc.get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "wait_any_frac_of_wave_cycles",
+                                                        "wait_inst_any_frac_of_wave_cycles", "source")}
+        else:
+            # no PMC table for this configuration / kernel: the HBM contract figure with the survey's literal bytes stays a bound <= 1
+            roofline.update({"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS, "achieved": hbm["algorithmic_survey_32B_nodes"],
+                             "frac": hbm["algorithmic_survey_frac"],
+                             "definition": "no committed PMC pass for this configuration: SURVEY 8(d) algorithmic bytes (32-B nodes) / launch time; "
+                                           "cache-served, not HBM traffic"})
+
+    # ---- latency of one rt_render_frame, camera fixed and camera moved before every frame (untimed extras, rank 0, N = 1)
+    latency = None
+    if world == 1 and not args.no_latency:
+        tr.reset_accum()
+        tr.render_frame(0)
+        t0 = time.perf_counter()
+        for f in range(1, 6):
+            tr.render_frame(f)
+        single = (time.perf_counter() - t0) / 5
+        moved = []
+        p2 = params.copy()
+        t0 = time.perf_counter()
+        for f in range(8):
+            p2["worldSpaceCameraPos"] = params["worldSpaceCameraPos"] + np.float32([0.002 * (f + 1), 0.0, 0.0])
+            m = p2["camLocalToWorld"].copy(); m[3] = params["camLocalToWorld"][3] + np.float32(0.002 * (f + 1)); p2["camLocalToWorld"] = m
+            tr.set_params(p2)
+            tr.reset_accum()                                   # a moved camera restarts the accumulation (RayTracingManager.Start)
+            tr.render_frame(0)
+        moving = (time.perf_counter() - t0) / 8
+        tr.set_params(params)
+        latency = {"latency_ms_single_frame": round(single * 1e3, 3), "latency_ms_single_frame_moving_camera": round(moving * 1e3, 3),
+                   "note": "wall time of one rt_render_frame (one launch, fused accumulate, stream sync); moving camera = rt_set_params with a "
+                           "new camera position + rt_reset_accum + rt_render_frame per frame, tile costs re-measured and re-sorted on the "
+                           "device every frame"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(rtx, buffers)
@@ -282,6 +341,9 @@ def main():
                    "per_gpu_kernel_ms": busy},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if latency:
+        out.update({k: v for k, v in latency.items() if k != "note"})
+        out["latency_note"] = latency["note"]
     print(json.dumps(out), flush=True)
 
 

@@ -233,6 +233,11 @@ int rt_reset_accum(rt_ctx* ctx);
  * last_frame = currentFrame (RayTracingManager.cs:33,75).                                             */
 int rt_read_accum     (rt_ctx* ctx, float* rgba, size_t n_floats);
 int rt_read_last_frame(rt_ctx* ctx, float* rgba, size_t n_floats);
+/* Restore a saved accumulation state: resultTexture + numRenderedFrames are all the reference carries from frame to frame
+ * (RayTracingManager.cs:26,33; the counter restarts in Start, :43-46).  rgba = rows*width*4 floats as returned by
+ * rt_read_accum; the next frame to render is frame index frames_rendered (frames are independent given their index,
+ * RayTracing.shader:362, so a resumed render equals an uninterrupted one bit for bit).                                  */
+int rt_write_accum(rt_ctx* ctx, const float* rgba, size_t n_floats, int frames_rendered);
 /* Device-side copy of the strip into caller-owned device memory (e.g. a torch tensor handed to RCCL). */
 int rt_copy_accum_to_device(rt_ctx* ctx, void* dst_device_ptr, size_t n_floats);
 

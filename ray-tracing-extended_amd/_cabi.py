@@ -55,7 +55,7 @@ SYMBOLS = [
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
     "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry", "rt_read_display",
-    "rt_read_bvh",
+    "rt_read_bvh", "rt_write_accum",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ def load_library() -> ctypes.CDLL:
     lib.rt_get_stats.argtypes = [c_void_p, c_void_p]
     lib.rt_read_display.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.rt_read_bvh.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.rt_write_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t, c_int]
     lib.rt_abi_version.restype = c_int
     lib.rt_sizeof.argtypes = [c_char_p]
     for n in SYMBOLS:
@@ -231,6 +232,11 @@ class Tracer:
         out = np.empty((rows, W, 4), np.float32)
         self._check(self._lib.rt_read_accum(self._ctx, out.ctypes.data_as(POINTER(c_float)), out.size), "rt_read_accum")
         return out
+
+    def write_accum(self, rgba, frames_rendered: int):
+        """Restore a saved resultTexture (as read_accum returned it) and the frame counter."""
+        a = np.ascontiguousarray(rgba, np.float32)
+        self._check(self._lib.rt_write_accum(self._ctx, a.ctypes.data_as(POINTER(c_float)), a.size, int(frames_rendered)), "rt_write_accum")
 
     def read_last_frame(self) -> np.ndarray:
         rows, W = self._strip_shape()

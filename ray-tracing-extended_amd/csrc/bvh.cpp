@@ -11,10 +11,6 @@
 namespace rtbvh {
 namespace {
 
-int g_bins = 32;            // SAH bins per axis (set_tuning)
-float g_cost_exp = 1.0f;    // the SAH's subtree-cost model: area * count^g_cost_exp
-int g_reinsert_passes = 0;  // insertion-based optimisation passes after the top-down build
-
 struct Box {
     float mn[3], mx[3];
     void reset()
@@ -51,6 +47,8 @@ struct Builder {
     std::vector<BNode>    bn;
     int depth = 0;
     int max_leaf = kMaxLeaf;
+    int g_bins = 32;            // SAH bins per axis (Tuning::bins)
+    float g_cost_exp = 1.0f;    // the SAH's subtree-cost model: area * count^g_cost_exp
 
     int build_range(uint32_t first, uint32_t count, int level)
     {
@@ -245,20 +243,17 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 
 } // namespace
 
-void set_tuning(int bins, int cost_exp_percent, int reinsert_passes)
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, const Tuning& tuning, Bvh& out)
 {
-    g_reinsert_passes = std::min(std::max(reinsert_passes, 0), 16);
-    g_bins = std::min(std::max(bins, 2), 128);
-    g_cost_exp = (float)std::min(std::max(cost_exp_percent, 10), 300) / 100.0f;
-}
-
-void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out)
-{
+    const int g_reinsert_passes = std::min(std::max(tuning.reinsert_passes, 0), 16);
+    const int max_leaf = tuning.max_leaf;
     out.nodes.clear(); out.order.clear(); out.maxStack = 0; out.depth = 0; out.levelStart.clear();
     if (n_tris == 0) return;
 
     Builder B; B.pos = tri_pos; B.stride = stride_floats; B.n = n_tris;
     B.max_leaf = std::min(std::max(max_leaf, 1), kMaxLeaf);
+    B.g_bins = std::min(std::max(tuning.bins, 2), 128);
+    B.g_cost_exp = (float)std::min(std::max(tuning.cost_exp_percent, 10), 300) / 100.0f;
     B.tbox.resize(n_tris); B.cent.resize(3 * (size_t)n_tris); B.idx.resize(n_tris);
     float G = origin_magnitude;
     for (uint32_t t = 0; t < n_tris; ++t) {

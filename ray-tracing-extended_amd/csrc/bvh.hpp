@@ -86,12 +86,13 @@ struct Bvh {
     std::vector<uint32_t> levelStart;       // nodes of tree level L are [levelStart[L], levelStart[L+1]) (breadth-first order)
 };
 
-// tri_pos: 9 floats per triangle (posA, posB, posC).  origin_magnitude = largest |coordinate| a ray origin outside
-// the geometry can have (the camera): it widens the absolute part of the box padding.
-// max_leaf: triangles per leaf (1..kMaxLeaf).
-// Builder tuning (process-wide): SAH bins per axis (2..128, default 32) and the exponent, in percent, of the triangle count in
-// the SAH's subtree-cost model area * count^e (default 100); passes of insertion-based optimisation of the binary tree.  The hierarchy changes, the closest hit it returns does not.
-void set_tuning(int bins, int cost_exp_percent, int reinsert_passes);
-void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, int max_leaf, Bvh& out);
+// Builder tuning, per call (two contexts on two host threads build independently): SAH bins per axis (2..128), the exponent,
+// in percent, of the triangle count in the SAH's subtree-cost model area * count^e, passes of insertion-based optimisation of
+// the binary tree, triangles per leaf (1..kMaxLeaf).  The hierarchy changes, the closest hit it returns does not.
+struct Tuning { int bins = 32; int cost_exp_percent = 100; int reinsert_passes = 0; int max_leaf = 2; };
+
+// tri_pos: 9 floats per triangle (posA, posB, posC) every stride_floats.  origin_magnitude = largest |coordinate| a ray origin
+// outside the triangles can have (the camera, sphere surfaces): it widens the absolute part of the box padding.
+void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, const Tuning& tuning, Bvh& out);
 
 } // namespace rtbvh

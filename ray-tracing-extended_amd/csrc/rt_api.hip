@@ -67,7 +67,7 @@ struct rt_ctx {
     std::vector<float>             mesh_radius;     // largest |local coordinate| * sqrt(3) per mesh
     int n_meshes = 0;
     DevBuf<float> d_local_tris;
-    DevBuf<uint32_t> d_tri_mesh, d_tri_chunk, d_order;
+    DevBuf<uint32_t> d_tri_mesh, d_tri_chunk, d_tri_rank, d_order;
     DevBuf<rtg::MeshXf> d_xf;
     hipEvent_t evg0 = nullptr, evg1 = nullptr;
 
@@ -77,7 +77,8 @@ struct rt_ctx {
     DevBuf<float4> d_frame, d_accum;
     DevBuf<uint32_t> d_display;
     DevBuf<float4> d_batch;            // per-frame outputs of a multi-frame launch
-    DevBuf<uint32_t> d_tile_order, d_tile_cost;
+    DevBuf<uint32_t> d_tile_order, d_tile_cost, d_tile_hist;
+    bool lpt_active = true;             // the last launch used (or could have used) a costliest-first order: the automatic kernel choice waits for it
     bool tile_order_valid = false, tile_order_stale = false; int tile_order_n = 0;   // stale: usable, re-measured by the next launch
     size_t target_pixels = 0;
     int target_w = 0, target_h = 0, target_row0 = 0, target_rows = 0, target_row_stride = 8;
@@ -159,6 +160,24 @@ int compact_nodes(rt_ctx* c)
     return 0;
 }
 
+// Bounce rays start on sphere surfaces too (Trace :327): the largest |coordinate| of any sphere surface point.
+float sphere_magnitude(const rt_ctx* c)
+{
+    float m = 0.f;
+    for (const rt_sphere& s : c->h_spheres) {
+        const float r = std::fabs(s.radius);
+        for (int a = 0; a < 3; ++a) { const float v = std::fabs(s.position[a]) + r; if (v > m && v < 3.0e38f) m = v; }
+    }
+    return m;
+}
+
+rtbvh::Tuning bvh_tuning(const rt_ctx* c)
+{
+    rtbvh::Tuning t;
+    t.bins = c->opt_bvh_bins; t.cost_exp_percent = c->opt_bvh_cost_exp; t.reinsert_passes = c->opt_bvh_reinsert; t.max_leaf = c->opt_max_leaf;
+    return t;
+}
+
 // Re-layout of the uploaded buffers + BVH build.  Edge vectors and their cross product are the operands of
 // RayTriangle (RayTracing.shader:152-154) evaluated once here with the same float operations.
 int build_scene(rt_ctx* c)
@@ -180,13 +199,20 @@ int build_scene(rt_ctx* c)
             slot = (uint32_t)m;
         }
     }
+    // equal-distance hits: the reference keeps the triangle its loops reach first — chunks in AllMeshInfo order, triangles in
+    // order inside the chunk (CalculateRayCollision :276-293).  That visiting rank, not the buffer index, is the tie-break key.
+    std::vector<uint32_t> visit_rank(nt, 0xFFFFFFFFu);
+    {
+        uint32_t r = 0;
+        for (size_t m = 0; m < nm; ++m)
+            for (uint32_t i = 0; i < c->h_mesh[m].numTriangles; ++i) visit_rank[c->h_mesh[m].firstTriangleIndex + i] = r++;
+    }
     // triangles outside every chunk are never visited by the shader: leave them out of the hierarchy
     std::vector<uint32_t> live; live.reserve(nt);
     for (size_t t = 0; t < nt; ++t) if (chunk_of[t] != 0xFFFFFFFFu) live.push_back((uint32_t)t);
     std::vector<float> pos(9 * live.size());
     for (size_t i = 0; i < live.size(); ++i) std::memcpy(&pos[9 * i], c->h_tris[live[i]].posA, 36);
-    rtbvh::set_tuning(c->opt_bvh_bins, c->opt_bvh_cost_exp, c->opt_bvh_reinsert);
-    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), camera_magnitude(c->params), c->opt_max_leaf, c->bvh);
+    rtbvh::build(pos.data(), 9, (uint32_t)live.size(), std::max(camera_magnitude(c->params), sphere_magnitude(c)), bvh_tuning(c), c->bvh);
 
     const size_t nl = live.size();
     std::vector<float4> geo(3 * nl), nrm(3 * nl);
@@ -200,7 +226,7 @@ int build_scene(rt_ctx* c)
         geo[3 * i + 1] = make_float4(ey, ez, fx, fy);
         geo[3 * i + 2] = make_float4(fz, nx, ny, nz);
         nrm[3 * i + 0] = make_float4(t.normalA[0], t.normalA[1], t.normalA[2], u2f(chunk_of[orig]));
-        nrm[3 * i + 1] = make_float4(t.normalB[0], t.normalB[1], t.normalB[2], u2f(orig));
+        nrm[3 * i + 1] = make_float4(t.normalB[0], t.normalB[1], t.normalB[2], u2f(visit_rank[orig]));
         nrm[3 * i + 2] = make_float4(t.normalC[0], t.normalC[1], t.normalC[2], 0.f);
     }
     std::vector<float4> sg(ns), sm(4 * ns), cm(4 * nm), cb(2 * nm);
@@ -245,7 +271,7 @@ int build_scene(rt_ctx* c)
 // Conservative bound of |coordinate| over camera-ray origins and the transformed meshes (box padding, bvh.cpp pad_box).
 float local_scene_magnitude(const rt_ctx* c)
 {
-    float G = camera_magnitude(c->params);
+    float G = std::max(camera_magnitude(c->params), sphere_magnitude(c));
     for (int m = 0; m < c->n_meshes; ++m) {
         const rt_mesh_transform& t = c->h_xf[m];
         float p = std::max(std::fabs(t.position[0]), std::max(std::fabs(t.position[1]), std::fabs(t.position[2])));
@@ -295,7 +321,7 @@ int run_geometry_kernels(rt_ctx* c, bool have_bvh)
     }
     if (have_bvh && nt) {
         hipLaunchKernelGGL(rtg::k_relayout, dim3((nt + 255) / 256), dim3(256), 0, c->stream,
-                           c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_geo.p, c->d_tri_nrm.p, nt);
+                           c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_rank.p, c->d_tri_geo.p, c->d_tri_nrm.p, nt);
         const float G = std::max(c->bvh.magnitude, local_scene_magnitude(c));
         c->bvh.magnitude = G;
         for (int L = (int)c->bvh.levelStart.size() - 2; L >= 0; --L) {
@@ -320,18 +346,22 @@ int build_scene_local(rt_ctx* c)
     const size_t nt = c->h_local_tris.size(), nm = c->h_lchunks.size();
     if ((int)c->h_xf.size() != c->n_meshes) return fail(c, -2, "rt_set_mesh_transforms has not been called for the %d meshes", c->n_meshes);
     { int r = upload_spheres_and_materials(c); if (r) return r; }
-    std::vector<uint32_t> tri_mesh(nt), tri_chunk(nt), range(2 * nm);
+    std::vector<uint32_t> tri_mesh(nt), tri_chunk(nt), tri_rank(nt), range(2 * nm);
     std::vector<float4> cm(4 * nm);
+    uint32_t rank = 0;
     for (size_t m = 0; m < nm; ++m) {
         const rt_local_chunk& ch = c->h_lchunks[m];
-        for (uint32_t i = 0; i < ch.numTriangles; ++i) { tri_mesh[ch.firstTriangleIndex + i] = ch.meshIndex; tri_chunk[ch.firstTriangleIndex + i] = (uint32_t)m; }
+        for (uint32_t i = 0; i < ch.numTriangles; ++i) {
+            tri_mesh[ch.firstTriangleIndex + i] = ch.meshIndex; tri_chunk[ch.firstTriangleIndex + i] = (uint32_t)m;
+            tri_rank[ch.firstTriangleIndex + i] = rank++;         // the reference's visiting order (chunk list order, then in-chunk order)
+        }
         range[2 * m] = ch.firstTriangleIndex; range[2 * m + 1] = ch.numTriangles;
         pack_material(ch.material, &cm[4 * m]);
     }
 #define RT_UP(buf, vec, T)                                                                                  \
     RT_HIP(c, buf.ensure(vec.size()));                                                                      \
     if (!vec.empty()) RT_HIP(c, hipMemcpyAsync(buf.p, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    RT_UP(c->d_tri_mesh, tri_mesh, uint32_t) RT_UP(c->d_tri_chunk, tri_chunk, uint32_t)
+    RT_UP(c->d_tri_mesh, tri_mesh, uint32_t) RT_UP(c->d_tri_chunk, tri_chunk, uint32_t) RT_UP(c->d_tri_rank, tri_rank, uint32_t)
     RT_UP(c->d_raw_range, range, uint32_t) RT_UP(c->d_chunk_mat, cm, float4)
 #undef RT_UP
     RT_HIP(c, c->d_local_tris.ensure(nt * 18)); RT_HIP(c, c->d_raw_tris.ensure(nt * 18));
@@ -342,15 +372,14 @@ int build_scene_local(rt_ctx* c)
     { int r = run_geometry_kernels(c, false); if (r) return r; }
     std::vector<rt_triangle> world(nt);
     if (nt) RT_HIP(c, hipMemcpy(world.data(), c->d_raw_tris.p, nt * sizeof(rt_triangle), hipMemcpyDeviceToHost));
-    rtbvh::set_tuning(c->opt_bvh_bins, c->opt_bvh_cost_exp, c->opt_bvh_reinsert);
-    rtbvh::build(nt ? world[0].posA : nullptr, 18, (uint32_t)nt, local_scene_magnitude(c), c->opt_max_leaf, c->bvh);
+    rtbvh::build(nt ? world[0].posA : nullptr, 18, (uint32_t)nt, local_scene_magnitude(c), bvh_tuning(c), c->bvh);
     RT_HIP(c, c->d_nodes.ensure(c->bvh.nodes.size() * 8)); RT_HIP(c, c->d_order.ensure(nt));
     if (!c->bvh.nodes.empty()) {
         RT_HIP(c, hipMemcpyAsync(c->d_nodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node4), hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync(c->d_order.p, c->bvh.order.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         { int r = compact_nodes(c); if (r) return r; }
         hipLaunchKernelGGL(rtg::k_relayout, dim3(((uint32_t)nt + 255) / 256), dim3(256), 0, c->stream,
-                           c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_geo.p, c->d_tri_nrm.p, (uint32_t)nt);
+                           c->d_raw_tris.p, c->d_order.p, c->d_tri_chunk.p, c->d_tri_rank.p, c->d_tri_geo.p, c->d_tri_nrm.p, (uint32_t)nt);
         RT_HIP(c, hipGetLastError());
     }
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -407,7 +436,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         if (c->scene_dirty) { int r = build_scene_local(c); if (r) return r; }
         else if (c->xf_dirty || local_scene_magnitude(c) > c->bvh.magnitude) { int r = run_geometry_kernels(c, true); if (r) return r; c->xf_dirty = false; }
     } else {
-        if (!c->scene_dirty && camera_magnitude(c->params) > c->bvh.magnitude) c->scene_dirty = true;   // re-pad the boxes
+        if (!c->scene_dirty && std::max(camera_magnitude(c->params), sphere_magnitude(c)) > c->bvh.magnitude) c->scene_dirty = true;   // re-pad the boxes
         if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
     }
     { int r = ensure_targets(c); if (r) return r; }
@@ -525,6 +554,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     // LPT scheduling of the persistent waves: a launch records every tile's cost; the next ones hand tiles out costliest
     // first, so the end of a launch is filled with cheap tiles instead of waiting for a few expensive ones.
     const bool lpt = (tile_kernel || (stream && c->opt_tile_sync) || waved) && c->opt_tile_lpt && ntiles > 1;
+    c->lpt_active = lpt;
     bool record_costs = false;
     if (lpt) {
         if (c->tile_order_n != ntiles) { c->tile_order_valid = false; c->tile_order_n = ntiles; }
@@ -574,11 +604,14 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     RT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.lastKernelMs = ms; c->stats.totalKernelMs += ms;
     if (record_costs) {
-        std::vector<uint32_t> cost(ntiles), order(ntiles);
-        RT_HIP(c, hipMemcpy(cost.data(), c->d_tile_cost.p, (size_t)ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (int t = 0; t < ntiles; ++t) order[t] = (uint32_t)t;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-        RT_HIP(c, hipMemcpy(c->d_tile_order.p, order.data(), (size_t)ntiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // costliest tiles first for the next launches: counting sort on the device, no host round trip
+        RT_HIP(c, c->d_tile_hist.ensure(rtg::kCostBuckets));
+        RT_HIP(c, hipMemsetAsync(c->d_tile_hist.p, 0, rtg::kCostBuckets * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(rtg::k_tile_hist, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream, c->d_tile_cost.p, (uint32_t)ntiles, c->d_tile_hist.p);
+        hipLaunchKernelGGL(rtg::k_tile_scan, dim3(1), dim3(1024), 0, c->stream, c->d_tile_hist.p);
+        hipLaunchKernelGGL(rtg::k_tile_scatter, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream, c->d_tile_cost.p, (uint32_t)ntiles,
+                           c->d_tile_hist.p, c->d_tile_order.p);
+        RT_HIP(c, hipGetLastError());
         c->tile_order_valid = true; c->tile_order_stale = false;
     }
     c->stats.numRenderedFrames += n_frames;
@@ -626,7 +659,9 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         }
         return launch_frames_k(c, first_frame, n_frames, var, kernel);
     }
-    if (c->auto_choice >= 0 && !c->scene_dirty && c->tile_order_valid)
+    // (with the costliest-first order switched off, or a single tile, there is no order to wait for)
+    auto order_ready = [&]() { return c->tile_order_valid || !c->lpt_active; };
+    if (c->auto_choice >= 0 && !c->scene_dirty && order_ready())
         return launch_frames_k(c, first_frame, n_frames, var, c->auto_choice);
 
     rt_stats sum{}; bool any = false;
@@ -639,11 +674,11 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     int done = 0;
     while (done < n_frames) {
         int kernel, count = 1;
-        if (c->scene_dirty || !c->tile_order_valid) { kernel = 0; c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }   // records the tile costs
+        if (c->scene_dirty || !order_ready()) { kernel = 0; c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }   // records the tile costs
         else if (c->auto_choice >= 0) { kernel = c->auto_choice; count = n_frames - done; }
         else if (c->auto_ms[0] < 0) kernel = 0;
         else kernel = 1;
-        const bool probing = c->auto_choice < 0 && !c->scene_dirty && c->tile_order_valid;
+        const bool probing = c->auto_choice < 0 && !c->scene_dirty && order_ready();
         int r = launch_frames_k(c, first_frame + done, count, var, kernel);
         if (r) return r;
         add();
@@ -733,14 +768,14 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evg0) (void)hipEventDestroy(c->evg0);
     if (c->evg1) (void)hipEventDestroy(c->evg1);
-    c->d_local_tris.release(); c->d_tri_mesh.release(); c->d_tri_chunk.release(); c->d_order.release(); c->d_xf.release();
+    c->d_local_tris.release(); c->d_tri_mesh.release(); c->d_tri_chunk.release(); c->d_tri_rank.release(); c->d_order.release(); c->d_xf.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -910,6 +945,23 @@ int rt_reset_accum(rt_ctx* c)
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0;
+    return 0;
+}
+
+int rt_write_accum(rt_ctx* c, const float* rgba, size_t n_floats, int frames_rendered)
+{
+    if (!c) return -1;
+    if (!rgba && n_floats) return fail(c, -2, "null source");
+    if (frames_rendered < 0) return fail(c, -2, "frames_rendered < 0");
+    if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
+    RT_HIP(c, hipSetDevice(c->device));
+    { int r = ensure_targets(c); if (r) return r; }
+    if (n_floats != c->target_pixels * 4) return fail(c, -2, "expected %zu floats (rows*width*4), got %zu", c->target_pixels * 4, n_floats);
+    if (n_floats) {
+        RT_HIP(c, hipMemcpyAsync(c->d_accum.p, rgba, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->stats.numRenderedFrames = frames_rendered;
     return 0;
 }
 

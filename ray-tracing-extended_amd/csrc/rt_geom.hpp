@@ -9,7 +9,7 @@
 //                    the operation order of UnityEngine's Quaternion * Vector3 so the bytes equal the host marshal's;
 //   k_chunk_bounds   tight world AABB per chunk, stored the way MeshInfo reads it back from a UnityEngine.Bounds
 //                    (centre/size round trip: RayTracedMesh.cs:82, MeshInfo.cs:16-17);
-//   k_relayout       BVH-order tracer records (A, eAB, eAC, cross | normals, chunk, original index);
+//   k_relayout       BVH-order tracer records (A, eAB, eAC, cross | normals, chunk, visiting rank);
 //   k_refit_level    bottom-up refit of the BVH4 boxes (topology kept), one launch per tree level.
 // All are streaming kernels: 240 B of HBM traffic per triangle end to end.
 #pragma once
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_chunk_bounds(const float* __restrict__ 
 
 // one thread per triangle in BVH order
 __global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ world_tris, const uint32_t* __restrict__ order,
-                                                  const uint32_t* __restrict__ tri_chunk, float4* __restrict__ tri_geo,
-                                                  float4* __restrict__ tri_nrm, uint32_t nl)
+                                                  const uint32_t* __restrict__ tri_chunk, const uint32_t* __restrict__ tri_rank,
+                                                  float4* __restrict__ tri_geo, float4* __restrict__ tri_nrm, uint32_t nl)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nl) return;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ worl
     tri_geo[3 * (size_t)i + 1] = make_float4(ey, ez, fx, fy);
     tri_geo[3 * (size_t)i + 2] = make_float4(fz, nx, ny, nz);
     tri_nrm[3 * (size_t)i + 0] = make_float4(t[9], t[10], t[11], __uint_as_float(tri_chunk[orig]));
-    tri_nrm[3 * (size_t)i + 1] = make_float4(t[12], t[13], t[14], __uint_as_float(orig));
+    tri_nrm[3 * (size_t)i + 1] = make_float4(t[12], t[13], t[14], __uint_as_float(tri_rank[orig]));   // tie-break key: visiting rank
     tri_nrm[3 * (size_t)i + 2] = make_float4(t[15], t[16], t[17], 0.f);
 }
 
@@ -172,6 +172,46 @@ __global__ __launch_bounds__(256) void k_compact_nodes(const rtbvh::Node4* __res
     for (int k = 0; k < 4; ++k) H.w[24 + k] = N.child[k];
     H.w[28] = __float_as_uint(O[0]); H.w[29] = __float_as_uint(O[1]); H.w[30] = __float_as_uint(O[2]); H.w[31] = 0u;
     out[i] = H;
+}
+
+// ---- costliest-first tile order on the device (LPT scheduling of the persistent waves): a counting sort of the tiles by the
+// cost the last launch recorded, 8192 buckets of 3 % width (exponent + 5 mantissa bits of the cost as a float), largest first.
+// Three tiny launches on the render stream instead of a device -> host copy, a host sort and a copy back: a camera that moves
+// every frame re-measures its tile costs every frame.  The order inside a bucket is whatever the atomics give; the image never
+// depends on the order.
+constexpr int kCostBuckets = 8192;
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t cost)
+{
+    const uint32_t b = __float_as_uint((float)cost) >> 18;           // <= (158 << 5 | 31) = 5087
+    return (uint32_t)(kCostBuckets - 1) - (b < (uint32_t)kCostBuckets ? b : (uint32_t)(kCostBuckets - 1));
+}
+__global__ __launch_bounds__(256) void k_tile_hist(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ hist)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+}
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ hist)      // one block: exclusive prefix sum in place
+{
+    __shared__ uint32_t part[1024];
+    constexpr int per = kCostBuckets / 1024;
+    uint32_t v[per], sum = 0;
+    for (int k = 0; k < per; ++k) { v[k] = hist[threadIdx.x * per + k]; sum += v[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int k = 0; k < per; ++k) { hist[threadIdx.x * per + k] = run; run += v[k]; }
+}
+__global__ __launch_bounds__(256) void k_tile_scatter(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ offsets,
+                                                      uint32_t* __restrict__ order)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&offsets[cost_bucket(cost[i])], 1u)] = i;
 }
 
 // ---- display step after the path: linear RGBA32F -> sRGB RGBA8 (the reference's final Blit(resultTexture, target) into an

@@ -31,7 +31,7 @@ struct DeviceScene {
     const float4* nodes;        // [nn*8]    rtbvh::Node4                                128 B
     const float4* nodes_h;      // [nn*8]    rtbvh::Node4h (f16 planes around a per-node origin: 5 loads per visit instead of 7)
     const float4* tri_geo;      // [nt*3]    BVH order: (A, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz) 48 B
-    const float4* tri_nrm;      // [nt*3]    BVH order: (nA, chunk) (nB, orig index) (nC, -)   48 B
+    const float4* tri_nrm;      // [nt*3]    BVH order: (nA, chunk) (nB, visiting rank = tie-break key) (nC, -)   48 B
     const float4* chunk_mat;    // [nm*4]    rt_material of the chunk                     64 B
     const float4* chunk_box;    // [nm*2]    (boundsMin, -) (boundsMax, -)                32 B
     // raw reference buffers for the flat validation kernel
@@ -288,6 +288,13 @@ __device__ __forceinline__ void load_tri(const float4* __restrict__ tri_geo, uin
     g2 = *reinterpret_cast<const float4*>(tb + (off + 32u));
 }
 
+// A ray with a NaN in it, or a zero direction, can hit nothing (every RaySphere / RayTriangle comparison is false), but its
+// slab tests are all NaN too and would "enter" every child, empty slots included: such a query is complete without traversal.
+__device__ __forceinline__ bool ray_traceable(v3 o, v3 d, float dd)
+{
+    return o.x == o.x && o.y == o.y && o.z == o.z && dd == dd && !(d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
+}
+
 // ---- closest hit: spheres, then BVH ---------------------------------------------------------------------
 template <bool COUNT, bool H = false>
 __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_mode, bool full_sort, v3 o, v3 d,
@@ -306,7 +313,7 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
         if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
     }
 
-    if (S.nn > 0) {
+    if (S.nn > 0 && ray_traceable(o, d, a)) {
         const RaySlabT<H> slab = make_slab<H>(o, d);
         const v3 inv = slab.inv;                                        // RayBoundingBox :179
         int sp = 0;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_pool(DeviceScene S, FrameArgs F, Poo
                                 if (COUNT) cnt.sph++;
                                 if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
                             }
-                            if (S.nn > 0) {
+                            if (S.nn > 0 && ray_traceable(o, d, a)) {
                                 slab = make_slab(o, d);
                                 cur = 0; sp = 0; fly = true;
                                 SLOT(SB, myslot) = (SLOT(SB, myslot) & ~15u) | FLY;

@@ -287,11 +287,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
                         }
                         live = true;
-                        // A ray with a NaN in it, or a zero direction, can hit nothing (every RaySphere / RayTriangle comparison
-                        // is false), but its slab tests are all NaN too and would "enter" every child, empty slots included:
-                        // such a query is complete as it stands.
-                        const bool traceable = o.x == o.x && o.y == o.y && o.z == o.z && a == a
-                                               && !(d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
+                        const bool traceable = ray_traceable(o, d, a);      // NaN / zero-direction rays are complete as they stand
                         if (S.nn > 0 && traceable) {
                             slab = make_slab<H>(o, d);                                  // RayBoundingBox :179
                             cur = 0; sp = 0; mode = kModeTrav;

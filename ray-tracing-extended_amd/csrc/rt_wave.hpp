@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
                         }
                         slab = make_slab(o, d);                                     // RayBoundingBox :179
-                        cur = S.nn > 0 ? 0u : kNone; sp = 0; fly = true;
+                        cur = (S.nn > 0 && ray_traceable(o, d, a)) ? 0u : kNone; sp = 0; fly = true;
                         sst[myslot] = (unsigned char)FLY;
                     }
                     pendNext += min(avail, __popcll(idle));

@@ -211,7 +211,7 @@ def mesh_test_scene(width: int = 96, height: int = 64, n_objects: int = 6, seed:
 # ---- configs[2..4]: the reference's Chess scene, instanced -------------------------------------------------------
 import os as _os
 
-GOLDEN_SCENES = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests", "golden", "scenes")
+CONFIGS_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "configs")     # frozen workload tables
 
 
 def chess_instanced(copies: int, width: int = 1920, height: int = 1080, columns: int = 5, spacing: float = 9.0,
@@ -221,7 +221,7 @@ def chess_instanced(copies: int, width: int = 1920, height: int = 1080, columns:
     quad, lit by the scene's invisible area light and its sky (sunIntensity 0, Chess.unity:30179-30185).
     copies = 17 -> 100,436 + 4 triangles (configs[2], [3]); copies = 170 -> 1,004,360 + 4 (configs[4])."""
     from .unity_scene import load_scene_npz
-    base = load_scene_npz(scene_path or _os.path.join(GOLDEN_SCENES, "Chess.npz"), width, height)
+    base = load_scene_npz(scene_path or _os.path.join(CONFIGS_DIR, "chess_scene.npz"), width, height)
     pieces = [m for m in base.meshes if m.triangleCount > 2]
     quads = [m for m in base.meshes if m.triangleCount <= 2]
     board = next(q for q in quads if q.materials[0].flag == MaterialFlag.CheckerPattern)
@@ -259,16 +259,43 @@ def chess_instanced(copies: int, width: int = 1920, height: int = 1080, columns:
     return mgr
 
 
-def config3(width: int = 1920, height: int = 1080) -> RayTracingManager:
+def workload_table() -> dict:
+    """configs/workloads.json: the frozen parameters of BASELINE.json's five configurations."""
+    import json
+    with open(_os.path.join(CONFIGS_DIR, "workloads.json")) as f:
+        return json.load(f)
+
+
+def _chess_workload(key: str, width: int, height: int) -> RayTracingManager:
+    w = workload_table()[key]
+    return chess_instanced(w["copies"], width or w["width"], height or w["height"], columns=w["columns"], spacing=w["spacing"],
+                           dof=w["dof"], bounces=w["bounces"])
+
+
+def config3(width: int = 0, height: int = 0) -> RayTracingManager:
     """configs[2]: ~100k triangles, 1920x1080, 1024 spp = 16 frames x 64 rays, 8 bounces, DOF off."""
-    return chess_instanced(17, width, height, bounces=8)
+    return _chess_workload("config3", width, height)
 
 
-def config4(width: int = 3840, height: int = 2160) -> RayTracingManager:
+def config4(width: int = 0, height: int = 0) -> RayTracingManager:
     """configs[3]: same scene, 3840x2160, 4096 spp = 64 frames x 64 rays, 12 bounces (8 GPUs, row strips)."""
-    return chess_instanced(17, width, height, bounces=12)
+    return _chess_workload("config4", width, height)
 
 
-def config5(width: int = 1920, height: int = 1080) -> RayTracingManager:
+def config5(width: int = 0, height: int = 0) -> RayTracingManager:
     """configs[4]: ~1.0M triangles (170 copies, 17 columns), DOF on (180 / 1 / 3.82), 1024 spp, 8 bounces."""
-    return chess_instanced(170, width, height, columns=17, bounces=8, dof=True)
+    return _chess_workload("config5", width, height)
+
+
+def sphere_table(mgr: RayTracingManager) -> list:
+    """The spheres of a manager as plain rows (configs/config1_spheres.json, config2_spheres.json hold the frozen ones)."""
+    _, spheres, _, _ = mgr.build_buffers()
+    rows = []
+    for s in spheres:
+        m = s["material"]
+        rows.append({"position": [float(v) for v in s["position"]], "radius": float(s["radius"]),
+                     "colour": [float(v) for v in m["colour"]], "emissionColour": [float(v) for v in m["emissionColour"]],
+                     "specularColour": [float(v) for v in m["specularColour"]], "emissionStrength": float(m["emissionStrength"]),
+                     "smoothness": float(m["smoothness"]), "specularProbability": float(m["specularProbability"]),
+                     "flag": int(m["flag"])})
+    return rows

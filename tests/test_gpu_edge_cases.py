@@ -157,3 +157,67 @@ def test_zero_normals_make_nan_rays_that_hit_nothing(rtx, oracle, tracer):
         acc, last = run_gpu(tracer, tuple(b), 1, 2, kernel=k)
         assert_bitwise(last, want_last, f"NaN rays, kernel {k}, last frame")
         assert_bitwise(acc, want, f"NaN rays, kernel {k}, accum")
+
+
+def test_resume_from_a_saved_accumulation_state(rtx, oracle, tracer):
+    """rt_write_accum: resultTexture + frame counter are the whole state the reference carries between frames
+    (RayTracingManager.cs:26,33); 3 frames, save, other work, restore, 4 more == 7 frames in one go == the oracle."""
+    b = rtx.scenes.config1(80, 48).build_buffers()
+    full, _ = run_gpu(tracer, b, 0, 7)
+    part, _ = run_gpu(tracer, b, 0, 3)
+    assert tracer.stats()["numRenderedFrames"] == 3
+    saved = part.copy()
+    tracer.reset_accum()
+    tracer.render(11, 2)                                  # unrelated frames in between
+    tracer.write_accum(saved, 3)
+    assert tracer.stats()["numRenderedFrames"] == 3
+    tracer.render(3, 4)
+    got = tracer.read_accum()
+    want, _, _ = oracle.render(*b, 0, 7)
+    assert_bitwise(got, full, "resumed render vs uninterrupted")
+    assert_bitwise(got, want, "resumed render vs oracle")
+    with pytest.raises(rtx.RtError):
+        tracer.write_accum(saved[:-1], 3)
+
+
+def test_nan_and_zero_direction_rays_do_not_walk_the_tree(rtx, oracle, tracer):
+    """Rays with a NaN in them (zero normals -> normalize(0) = NaN) or a zero direction complete without traversal in every
+    kernel: node visits per ray stay at the level of the traceable rays, and the images are the oracle's."""
+    m = rtx.scenes.mesh_test_scene(48, 32)
+    params, spheres, tris, infos = m.build_buffers()
+    tris = tris.copy()
+    for f in ("normalA", "normalB", "normalC"):
+        tris[f] = 0.0                                     # every triangle hit makes a NaN bounce ray
+    b = (params, spheres, tris, infos)
+    want, want_last, cnt = oracle.render(*b, 0, 2)
+    for kernel in (0, 1, 2, 3):
+        tracer.set_option("kernel", kernel)
+        tracer.set_params(params); tracer.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+        tracer.set_rows(0, int(params["height"]))
+        tracer.reset_accum()
+        tracer.render_counting(0, 2)
+        st = tracer.stats()
+        assert_bitwise(tracer.read_accum(), want, f"kernel {kernel}: NaN-ray scene")
+        assert st["rays"] == cnt["rays"]
+        nn = st["numBvhNodes"]
+        # a NaN ray that walked the tree would visit all nn nodes; traceable rays visit a few dozen at most
+        assert st["nodeVisits"] < st["rays"] * min(nn, 60), (kernel, st["nodeVisits"], st["rays"], nn)
+    tracer.set_option("kernel", 0)
+
+
+def test_automatic_kernel_choice_without_the_costliest_first_order(rtx, oracle, tracer):
+    """tile_lpt = 0: there is no tile order to wait for; the automatic choice still measures both kernels on the first frames,
+    decides, and batches the rest (it used to stay on single-frame k_trace launches for ever)."""
+    b = rtx.scenes.mesh_test_scene(96, 64).build_buffers()
+    tracer.set_option("tile_lpt", 0)
+    try:
+        acc, last = run_gpu(tracer, b, 0, 9, kernel=-1)
+        st = tracer.stats()
+        assert st["autoKernel"] in (0, 1)
+        tracer.render(9, 8)
+        assert tracer.stats()["lastFramesPerLaunch"] == 8
+        acc = tracer.read_accum()
+    finally:
+        tracer.set_option("tile_lpt", 1)
+    want, _, _ = oracle.render(*b, 0, 17)
+    assert_bitwise(acc, want, "auto kernel, tile_lpt = 0")

@@ -55,6 +55,39 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
 
 
+def test_product_reads_nothing_from_tests():
+    """The product package carries its own workload tables (configs/); it never reaches into tests/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ray-tracing-extended_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", ".cs")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"tests[/\\\"', ]+golden|\"tests\"", txt):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_frozen_workload_tables(rtx):
+    """configs/: the sphere tables equal what the generators produce, the chess data equals the converted reference scene, and
+    the five workloads have the sizes BASELINE.json names."""
+    cdir = os.path.join(ROOT, "ray-tracing-extended_amd", "configs")
+    for key, gen in (("config1", rtx.scenes.config1), ("config2", rtx.scenes.config2)):
+        assert json.load(open(os.path.join(cdir, f"{key}_spheres.json"))) == rtx.scenes.sphere_table(gen())
+    a = np.load(os.path.join(cdir, "chess_scene.npz"))
+    b = np.load(os.path.join(GOLDEN, "scenes", "Chess.npz"))
+    assert sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k], b[k]) for k in a.files)
+    w = rtx.scenes.workload_table()
+    assert (w["config1"]["width"], w["config1"]["raysPerPixel"], w["config1"]["bounces"]) == (256, 4, 3)
+    assert (w["config2"]["width"], w["config2"]["height"], w["config2"]["raysPerPixel"] * w["config2"]["frames"]) == (1920, 1080, 256)
+    assert (w["config3"]["raysPerPixel"] * w["config3"]["frames"], w["config3"]["bounces"]) == (1024, 8)
+    assert (w["config4"]["width"], w["config4"]["height"], w["config4"]["raysPerPixel"] * w["config4"]["frames"], w["config4"]["bounces"]) == (3840, 2160, 4096, 12)
+    assert w["config5"]["dof"] and w["config5"]["copies"] == 170
+    for key, gen in (("config1", rtx.scenes.config1), ("config2", rtx.scenes.config2), ("config3", rtx.scenes.config3)):
+        p = gen().build_buffers()[0]
+        assert (int(p["width"]), int(p["height"]), int(p["numRaysPerPixel"]), int(p["maxBounceCount"])) == \
+               (w[key]["width"], w[key]["height"], w[key]["raysPerPixel"], w[key]["bounces"])
+
+
 def test_scene_fixtures_match_totals_serialised_by_the_reference(rtx):
     """numMeshChunks / numTriangles written into each .unity by CreateMeshes (RayTracingManager.cs:156-157)."""
     from rtx_amd import unity_scene

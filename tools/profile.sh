@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-ARGS="--steps 8 --warmup 8 --no-cpu-baseline --no-roofline $*"
+ARGS="--steps 16 --warmup 16 --no-cpu-baseline --no-roofline --no-latency $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 echo "[profile] stats done"

@@ -6,8 +6,8 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb"); std::vector<float> v; float x; while (fread(&x, 4, 1, f) == 1) v.push_back(x); fclose(f);
     uint32_t n = v.size() / 9;
     // the API filters triangles with non-finite positions? emulate: pass all
-    rtbvh::Bvh b; rtbvh::set_tuning(32, 100, argc > 2 ? atoi(argv[2]) : 0);
-    rtbvh::build(v.data(), 9, n, 10.0f, 2, b);
+    rtbvh::Bvh b; rtbvh::Tuning t; t.reinsert_passes = argc > 2 ? atoi(argv[2]) : 0;
+    rtbvh::build(v.data(), 9, n, 10.0f, t, b);
     printf("tris %u nodes %zu maxStack %d depth %d\n", n, b.nodes.size(), b.maxStack, b.depth);
     return 0;
 }
