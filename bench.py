@@ -217,7 +217,7 @@ def main():
     roofline = None
     kernel_names = ({1: "k_stream<false,true,{H}>"} if args.rng == "philox" else
                     {0: "k_trace<false,false,false,{H}>", 1: "k_stream<false,false,{H}>", 2: "k_pool<false>", 3: "k_wave<false>"})
-    chosen = st.get("autoKernel", -1) if args.kernel < 0 else args.kernel
+    chosen = st.get("lastKernel", -1)                    # the kernel that ran the timed launches
     opts = dict(kv.split("=") for kv in args.opt)
     compact = int(opts.get("compact_nodes", 1)) != 0
     kernel_name = kernel_names.get(chosen, "k_trace<false,false,true,{H}>" if args.rng == "philox" else "k_trace<false,false,false,{H}>").replace(
@@ -255,7 +255,7 @@ def main():
                "measured_frac": round(traffic / launch_s / 1e9 / PEAK_HBM_GBPS, 5) if traffic else None}
         hbm["algorithmic_survey_frac"] = round(hbm["algorithmic_survey_32B_nodes"] / PEAK_HBM_GBPS, 5)
         roofline = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_VALU_TFLOPS, "achieved": None, "frac": None,
-                    "traffic": traffic, "kernel": kernel_name, "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl,
+                    "traffic": traffic, "kernel": kernel_name, "frames_interleaved_per_wave": st.get("lastFramesInterleaved", 1), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl,
                     "launches": launches, "algorithmic_bytes_per_launch": int(loaded),
                     "definition": "bound = VALU issue: achieved = VALU wave-instructions/s (SQ_INSTS_VALU per frame from the committed "
                                   "rocprofv3 pass x frames / launch time measured here) x 64 lanes x 2, against the FP32 vector peak; "

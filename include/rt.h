@@ -134,7 +134,9 @@ typedef struct rt_stats {
     double   lastGeometryMs;            /* HIP-event time of the last on-device transform + bounds + re-layout + refit */
     double   lastDisplayMs;             /* HIP-event time of the last linear -> sRGB8 display kernel     */
     int32_t  lastFramesPerLaunch;       /* frames traced per k_trace launch in the last rt_render (1 = frame by frame) */
-    int32_t  autoKernel;                /* kernel picked by the automatic choice (-1 = not decided yet / not automatic) */
+    int32_t  autoKernel;                /* kernel the automatic choice picked for single-frame launches (-1 = not decided yet / not automatic) */
+    int32_t  lastKernel;                /* kernel that ran the last launch: 0 k_trace, 1 k_stream, 2 k_pool, 3 k_wave, 4 flat twin */
+    int32_t  lastFramesInterleaved;     /* k_stream: frames interleaved in a wave by the last launch (1, 4 or 16)        */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -40,6 +40,7 @@ STATS = np.dtype([
     ("rays", "<u8"), ("sphereTests", "<u8"), ("nodeVisits", "<u8"), ("triTests", "<u8"), ("hits", "<u8"),
     ("phaseLanes", "<u8", 5), ("phaseExecs", "<u8", 5),
     ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"), ("lastGeometryMs", "<f8"), ("lastDisplayMs", "<f8"), ("lastFramesPerLaunch", "<i4"), ("autoKernel", "<i4"),
+    ("lastKernel", "<i4"), ("lastFramesInterleaved", "<i4"),
 ])
 MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])
 LOCAL_CHUNK = np.dtype([("firstTriangleIndex", "<u4"), ("numTriangles", "<u4"), ("meshIndex", "<u4"), ("_reserved", "<u4"),

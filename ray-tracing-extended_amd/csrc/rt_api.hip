@@ -578,6 +578,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
             while (fg > 0 && nb < (1 << fg)) fg -= 2;            // the largest group the rest of the render fills
             nb -= nb % (1 << fg);
             A.fg_log2 = fg;
+            // big groups only while every wave still gets at least ~8 of them: a single frame has 8 tiles per wave in all, and
+            // groups of 4 would end the launch on a few waves (measured: 38.7 ms instead of 24 ms for one 1080p frame)
+            const size_t items = (size_t)ntiles * (size_t)nb, waves = (size_t)grid * rtk::kWavesPerBlock;
+            A.tiles_per_fetch = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, std::min(16, c->opt_tiles_per_fetch)), items / (waves * 8)));
         }
         F.frame = first_frame + i;
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
@@ -598,6 +602,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         i += nb;
     }
     c->stats.lastFramesPerLaunch = batch;
+    c->stats.lastKernel = var == Variant::Flat ? 4 : waved ? 3 : pooled ? 2 : stream ? 1 : 0;
+    c->stats.lastFramesInterleaved = stream ? (1 << A.fg_log2) : 1;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
@@ -661,8 +667,12 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     }
     // (with the costliest-first order switched off, or a single tile, there is no order to wait for)
     auto order_ready = [&]() { return c->tile_order_valid || !c->lpt_active; };
+    // Decided: single frames go to the kernel that won the single-frame timing; launches of 4 frames or more over a BVH go to
+    // k_stream, whose frame-interleaved items (2x2 pixels x 16 frames per wave) have no counterpart in k_trace (measured on both
+    // triangle workloads: +13 % / +10 % over its own 8x8 x 1 items, which is what the single-frame timing compares)
+    auto decided = [&](int frames) { return (c->stats.numBvhNodes > 0 && frames >= 4 && c->opt_tile_sync) ? 1 : c->auto_choice; };
     if (c->auto_choice >= 0 && !c->scene_dirty && order_ready())
-        return launch_frames_k(c, first_frame, n_frames, var, c->auto_choice);
+        return launch_frames_k(c, first_frame, n_frames, var, decided(n_frames));
 
     rt_stats sum{}; bool any = false;
     auto add = [&]() {
@@ -675,7 +685,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     while (done < n_frames) {
         int kernel, count = 1;
         if (c->scene_dirty || !order_ready()) { kernel = 0; c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }   // records the tile costs
-        else if (c->auto_choice >= 0) { kernel = c->auto_choice; count = n_frames - done; }
+        else if (c->auto_choice >= 0) { count = n_frames - done; kernel = decided(count); }
         else if (c->auto_ms[0] < 0) kernel = 0;
         else kernel = 1;
         const bool probing = c->auto_choice < 0 && !c->scene_dirty && order_ready();
