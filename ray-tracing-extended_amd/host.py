@@ -178,20 +178,41 @@ class RayTracedSphere:
     material: RayTracingMaterial = field(default_factory=RayTracingMaterial)
 
 
+class Mesh:
+    """What MeshSplitter reads of a UnityEngine.Mesh (MeshSplitter.cs:15-23): vertices, normals, the index buffer
+    (`triangles`) and the sub-mesh ranges [(indexStart, indexCount)]."""
+
+    def __init__(self, vertices, normals, triangles, subMeshes=None):
+        self.vertices = np.asarray(vertices, np.float32).reshape(-1, 3)
+        self.normals = np.asarray(normals, np.float32).reshape(-1, 3)
+        self.triangles = np.asarray(triangles, np.int32).reshape(-1)
+        self.subMeshes = [(0, len(self.triangles))] if subMeshes is None else [(int(a), int(b)) for a, b in subMeshes]
+
+
 class RayTracedMesh:
-    def __init__(self, transform: Transform, materials: List[RayTracingMaterial], localChunks: List[MeshChunk],
-                 triangleCount: Optional[int] = None, enforceTriangleLimit: bool = True):
+    def __init__(self, transform: Transform, materials: List[RayTracingMaterial], localChunks: Optional[List[MeshChunk]] = None,
+                 triangleCount: Optional[int] = None, enforceTriangleLimit: bool = True, sharedMesh: Optional[Mesh] = None):
         self.transform = transform
         self.materials = materials
-        self.localChunks = localChunks
-        self.triangleCount = sum(len(c.triangles) for c in localChunks) if triangleCount is None else triangleCount
+        self.localChunks = localChunks              # [SerializeField]: the scenes carry them; None = not split yet
+        self.mesh: Optional[Mesh] = None            # [SerializeField] Mesh mesh: what the cached chunks were made from
+        self.sharedMesh = sharedMesh                # meshFilter.sharedMesh (None: no MeshFilter — only serialised chunks)
+        if triangleCount is None:
+            triangleCount = sum(len(c.triangles) for c in localChunks) if localChunks else (len(sharedMesh.triangles) // 3 if sharedMesh else 0)
+        self.triangleCount = triangleCount
         self.enforceTriangleLimit = enforceTriangleLimit
         self.worldChunks: Optional[List[MeshChunk]] = None
 
     def GetSubMeshes(self) -> List[MeshChunk]:
         """RayTracedMesh.cs:17-54 — chunks in world space (every triangle re-transformed on the host)."""
-        if self.enforceTriangleLimit and self.triangleCount > RayTracingManager.TriangleLimit:
+        meshTriangles = len(self.mesh.triangles) // 3 if self.mesh is not None else self.triangleCount      # :19
+        if self.enforceTriangleLimit and meshTriangles > RayTracingManager.TriangleLimit:
             raise Exception(f"Please use a mesh with fewer than {RayTracingManager.TriangleLimit} triangles")
+        # Split mesh into chunks (if result is not already cached)  :24-29
+        if self.sharedMesh is not None and (self.mesh is not self.sharedMesh or not self.localChunks):
+            self.mesh = self.sharedMesh
+            self.localChunks = MeshSplitter.CreateChunks(self.mesh)
+            self.triangleCount = len(self.mesh.triangles) // 3
         pos, rot, scale = self.transform.position, self.transform.rotation, self.transform.lossyScale
         self.worldChunks = [self._UpdateWorldChunkFromLocal(c, pos, rot, scale) for c in self.localChunks]
         return self.worldChunks
@@ -447,8 +468,20 @@ class MeshSplitter:
         return MeshChunk(triangles.copy(), b, subMeshIndex)
 
     @staticmethod
-    def CreateChunks(sub_meshes) -> list:
-        """:11-33 — `sub_meshes` = [(TRIANGLE[n], subMeshIndex)] in sub-mesh order."""
+    def CreateChunks(mesh) -> list:
+        """:11-33 — `mesh` is a Mesh (vertices, normals, index buffer, sub-mesh ranges), or directly the sub-meshes'
+        triangle lists [(TRIANGLE[n], subMeshIndex)] in sub-mesh order."""
+        if isinstance(mesh, Mesh):
+            sub_meshes = []
+            for i, (start, count) in enumerate(mesh.subMeshes):
+                idx = mesh.triangles[start:start + count].reshape(-1, 3)
+                t = np.zeros(len(idx), TRIANGLE)
+                for k, (pf, nf) in enumerate((("posA", "normalA"), ("posB", "normalB"), ("posC", "normalC"))):
+                    t[pf] = mesh.vertices[idx[:, k]]
+                    t[nf] = mesh.normals[idx[:, k]]
+                sub_meshes.append((t, i))
+        else:
+            sub_meshes = mesh
         out = []
         for tris, idx in sub_meshes:
             MeshSplitter.Split(MeshSplitter.CreateSubMesh(tris, idx), out)

@@ -53,10 +53,133 @@ Vector3 Light::worldSpaceLightPos0() const
     return { -f.x, -f.y, -f.z };
 }
 
-std::vector<MeshChunk> RayTracedMesh::GetSubMeshes() const
+// ---- MeshSplitter (Assets/Scripts/Helpers/MeshSplitter.cs) --------------------------------------------------------------
+namespace MeshSplitter {
+namespace {
+
+struct UBounds {            // UnityEngine.Bounds: centre + extents, float32
+    float c[3], e[3];
+    UBounds(const float* center, const float* size) { for (int a = 0; a < 3; ++a) { c[a] = center[a]; e[a] = size[a] * 0.5f; } }
+    float mn(int a) const { return c[a] - e[a]; }
+    float mx(int a) const { return c[a] + e[a]; }
+    float size(int a) const { return e[a] * 2.0f; }
+    void Encapsulate(const float* p)            // SetMinMax(Vector3.Min(min, p), Vector3.Max(max, p))
+    {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(mn(a), p[a]); hi[a] = std::max(mx(a), p[a]); }
+        for (int a = 0; a < 3; ++a) { e[a] = (hi[a] - lo[a]) * 0.5f; c[a] = lo[a] + e[a]; }
+    }
+    bool Contains(const float* p) const
+    {
+        for (int a = 0; a < 3; ++a) if (!(p[a] >= mn(a) && p[a] <= mx(a))) return false;
+        return true;
+    }
+    Bounds toBounds() const { return { { c[0], c[1], c[2] }, { size(0), size(1), size(2) } }; }
+};
+
+UBounds fromBounds(const Bounds& b)
 {
-    if (enforceTriangleLimit && triangleCount > RayTracingManager::TriangleLimit)
+    const float c[3] = { b.center.x, b.center.y, b.center.z }, s[3] = { b.size.x, b.size.y, b.size.z };
+    return UBounds(c, s);
+}
+
+MeshChunk Extract(const std::vector<rt_triangle>& triangles, std::vector<char>& taken, const UBounds& splitBounds, int subMeshIndex)   // :101-124
+{
+    MeshChunk out; out.subMeshIndex = subMeshIndex;
+    const float sz[3] = { splitBounds.size(0), splitBounds.size(1), splitBounds.size(2) };
+    UBounds nb(splitBounds.c, sz);
+    for (size_t i = 0; i < triangles.size(); ++i) {
+        if (taken[i]) continue;
+        const rt_triangle& t = triangles[i];
+        if (splitBounds.Contains(t.posA) || splitBounds.Contains(t.posB) || splitBounds.Contains(t.posC)) {
+            nb.Encapsulate(t.posA); nb.Encapsulate(t.posB); nb.Encapsulate(t.posC);
+            out.triangles.push_back(t);
+            taken[i] = 1;
+        }
+    }
+    out.bounds = nb.toBounds();
+    return out;
+}
+
+} // namespace
+
+MeshChunk CreateSubMeshFromTriangles(const std::vector<rt_triangle>& triangles, const Vector3& firstVertex, int subMeshIndex)
+{
+    const float v0[3] = { firstVertex.x, firstVertex.y, firstVertex.z }, seed[3] = { 0.01f, 0.01f, 0.01f };
+    UBounds b(v0, seed);                                                         // new Bounds(verts[indices[0]], Vector3.one * 0.01f)  :39
+    for (const rt_triangle& t : triangles) { b.Encapsulate(t.posA); b.Encapsulate(t.posB); b.Encapsulate(t.posC); }
+    MeshChunk c; c.triangles = triangles; c.bounds = b.toBounds(); c.subMeshIndex = subMeshIndex;
+    return c;
+}
+
+MeshChunk CreateSubMesh(const Mesh& mesh, int indexStart, int indexCount, int subMeshIndex)
+{
+    if (indexStart < 0 || indexCount < 0 || (size_t)indexStart + (size_t)indexCount > mesh.triangles.size())
+        throw std::runtime_error("sub-mesh index range outside the index buffer");
+    if (indexCount < 3) throw std::runtime_error("sub-mesh without triangles");          // verts[indices[0]] would throw in C# too
+    std::vector<rt_triangle> tris((size_t)indexCount / 3);
+    auto vert = [&](int i) -> const Vector3& {
+        if (i < 0 || (size_t)i >= mesh.vertices.size() || (size_t)i >= mesh.normals.size()) throw std::runtime_error("vertex index outside the mesh");
+        return mesh.vertices[(size_t)i];
+    };
+    for (int i = 0; i + 2 < indexCount; i += 3) {
+        float* const f = reinterpret_cast<float*>(&tris[(size_t)i / 3]);          // posA posB posC normalA normalB normalC
+        for (int k = 0; k < 3; ++k) {
+            const int idx = mesh.triangles[(size_t)indexStart + (size_t)i + (size_t)k];
+            const Vector3& p = vert(idx); const Vector3& n = mesh.normals[(size_t)idx];
+            f[3 * k] = p.x; f[3 * k + 1] = p.y; f[3 * k + 2] = p.z;
+            f[9 + 3 * k] = n.x; f[9 + 3 * k + 1] = n.y; f[9 + 3 * k + 2] = n.z;
+        }
+    }
+    return CreateSubMeshFromTriangles(tris, vert(mesh.triangles[(size_t)indexStart]), subMeshIndex);
+}
+
+void Split(const MeshChunk& chunk, std::vector<MeshChunk>& splitChunks, int depth)
+{
+    if ((int)chunk.triangles.size() > maxTrisPerChunk && depth < maxDepth) {
+        const UBounds b = fromBounds(chunk.bounds);
+        const float q[3] = { b.size(0) / 4.0f, b.size(1) / 4.0f, b.size(2) / 4.0f };
+        std::vector<char> taken(chunk.triangles.size(), 0);
+        size_t nTaken = 0;
+        for (int x = -1; x <= 1; x += 2)
+            for (int y = -1; y <= 1; y += 2)
+                for (int z = -1; z <= 1; z += 2) {
+                    if (chunk.triangles.size() - nTaken == 0) continue;
+                    const float centre[3] = { b.c[0] + q[0] * (float)x, b.c[1] + q[1] * (float)y, b.c[2] + q[2] * (float)z };
+                    const float size[3] = { q[0] * 2.0f, q[1] * 2.0f, q[2] * 2.0f };
+                    const UBounds splitBounds(centre, size);
+                    MeshChunk sub = Extract(chunk.triangles, taken, splitBounds, chunk.subMeshIndex);
+                    nTaken += sub.triangles.size();
+                    if (!sub.triangles.empty()) Split(sub, splitChunks, depth + 1);
+                }
+    } else {
+        splitChunks.push_back(chunk);
+    }
+}
+
+std::vector<MeshChunk> CreateChunks(const Mesh& mesh)
+{
+    std::vector<MeshChunk> subMeshes;
+    for (size_t i = 0; i < mesh.subMeshes.size(); ++i)
+        subMeshes.push_back(CreateSubMesh(mesh, mesh.subMeshes[i].indexStart, mesh.subMeshes[i].indexCount, (int)i));
+    std::vector<MeshChunk> out;
+    for (const MeshChunk& sm : subMeshes) Split(sm, out);
+    return out;
+}
+
+} // namespace MeshSplitter
+
+std::vector<MeshChunk> RayTracedMesh::GetSubMeshes()
+{
+    const int meshTriangles = mesh ? (int)(mesh->triangles.size() / 3) : triangleCount;     // mesh.triangles.Length / 3  (:19)
+    if (enforceTriangleLimit && meshTriangles > RayTracingManager::TriangleLimit)
         throw std::runtime_error("Please use a mesh with fewer than " + std::to_string(RayTracingManager::TriangleLimit) + " triangles");
+    // Split mesh into chunks (if result is not already cached)  :24-29
+    if (sharedMesh != nullptr && (mesh != sharedMesh || localChunks.empty())) {
+        mesh = sharedMesh;
+        localChunks = MeshSplitter::CreateChunks(*mesh);
+        triangleCount = (int)(mesh->triangles.size() / 3);
+    }
     std::vector<MeshChunk> world(localChunks.size());
     const Vector3 pos = transform.position, scale = transform.lossyScale;
     const Quaternion rot = transform.rotation;
@@ -149,7 +272,7 @@ std::vector<rt_sphere> RayTracingManager::CreateSpheres() const
 void RayTracingManager::CreateMeshes(std::vector<rt_triangle>& tris, std::vector<rt_meshinfo>& infos)
 {
     tris.clear(); infos.clear();
-    for (const RayTracedMesh& mesh : meshes) {
+    for (RayTracedMesh& mesh : meshes) {
         for (const MeshChunk& chunk : mesh.GetSubMeshes()) {
             rt_meshinfo mi{};
             mi.firstTriangleIndex = (uint32_t)tris.size(); mi.numTriangles = (uint32_t)chunk.triangles.size();

@@ -3,6 +3,7 @@
 //   RayTracingMaterial   Assets/Scripts/Data Types/RayTracingMaterial.cs:4-29       (= rt_material, 64 B)
 //   EnvironmentSettings  Assets/Scripts/Data Types/EnvironmentSettings.cs:4-11
 //   MeshChunk            Assets/Scripts/Data Types/MeshChunk.cs:6-17
+//   MeshSplitter         Assets/Scripts/Helpers/MeshSplitter.cs:8-124               (CreateChunks, CreateSubMesh, Split, Extract)
 //   RayTracedSphere      "Assets/Scripts/Render Types/RayTracedSphere.cs":5-7
 //   RayTracedMesh        "Assets/Scripts/Render Types/RayTracedMesh.cs":17-99       (GetSubMeshes, GetMaterial)
 //   RayTracingManager    Assets/Scripts/RayTracingManager.cs:11-203                  (settings, CreateSpheres, CreateMeshes,
@@ -43,6 +44,28 @@ struct Bounds {                     // UnityEngine.Bounds as constructed with (c
 
 struct MeshChunk { std::vector<rt_triangle> triangles; Bounds bounds; int subMeshIndex = 0; };
 
+// What MeshSplitter reads of a UnityEngine.Mesh: vertices, normals, the index buffer and the sub-mesh ranges
+// (mesh.vertices / normals / triangles / GetSubMesh(i).indexStart, indexCount — MeshSplitter.cs:15-23).
+struct Mesh {
+    struct SubMeshDescriptor { int indexStart = 0, indexCount = 0; };
+    std::vector<Vector3> vertices, normals;
+    std::vector<int> triangles;
+    std::vector<SubMeshDescriptor> subMeshes;
+};
+
+// MeshSplitter.cs: recursive 8-octant split until <= 48 triangles or depth 6; a triangle goes to the first octant (x, then y,
+// then z loop order) that contains one of its vertices.  UnityEngine.Bounds is restated in float32 as centre + extents
+// (Encapsulate(p) = SetMinMax(Min(min, p), Max(max, p)), re-deriving centre and extents after every point).
+namespace MeshSplitter {
+constexpr int maxDepth = 6;             // MeshSplitter.cs:8
+constexpr int maxTrisPerChunk = 48;     // MeshSplitter.cs:9
+std::vector<MeshChunk> CreateChunks(const Mesh& mesh);                                                       // :11-33
+MeshChunk CreateSubMesh(const Mesh& mesh, int indexStart, int indexCount, int subMeshIndex);                 // :35-63
+// the same from an explicit triangle list and seed vertex (the 0.01-sized box of :39 sits at the sub-mesh's first vertex)
+MeshChunk CreateSubMeshFromTriangles(const std::vector<rt_triangle>& triangles, const Vector3& firstVertex, int subMeshIndex);
+void Split(const MeshChunk& chunk, std::vector<MeshChunk>& splitChunks, int depth = 0);                      // :65-99
+}
+
 struct EnvironmentSettings {
     bool enabled = false;       // colours are kept as parsed (double): Material.SetColor's sRGB -> linear runs on them
     double groundColour[4] = {0, 0, 0, 0}, skyColourHorizon[4] = {0, 0, 0, 0}, skyColourZenith[4] = {0, 0, 0, 0};
@@ -57,10 +80,14 @@ struct RayTracedSphere { Transform transform; RayTracingMaterial material{}; };
 struct RayTracedMesh {
     Transform transform;
     std::vector<RayTracingMaterial> materials;
-    std::vector<MeshChunk> localChunks;
+    std::vector<MeshChunk> localChunks;         // [SerializeField]: the scenes carry them; empty = not split yet
+    const Mesh* mesh = nullptr;                 // [SerializeField] Mesh mesh: the mesh the cached chunks were made from
+    const Mesh* sharedMesh = nullptr;           // meshFilter.sharedMesh (null: no MeshFilter — only the serialised chunks exist)
     int triangleCount = 0;
     bool enforceTriangleLimit = true;
-    std::vector<MeshChunk> GetSubMeshes() const;                                 // RayTracedMesh.cs:17-54 (throws > 1500 tris)
+    // RayTracedMesh.cs:17-54: throws above 1500 triangles; splits the mesh when there is no cached result for it (:24-29);
+    // returns the chunks in world space
+    std::vector<MeshChunk> GetSubMeshes();
     const RayTracingMaterial& GetMaterial(int subMeshIndex) const;               // :96-99
 };
 

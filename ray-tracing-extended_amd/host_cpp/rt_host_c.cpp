@@ -65,4 +65,60 @@ int rth_render(void* hp, int device, int frames, float* rgba)
     return rc;
 }
 
+// ---- MeshSplitter / RayTracedMesh.GetSubMeshes through plain arrays (tests) --------------------------------------------
+// verts / normals: n_verts x 3 floats; indices: the index buffer; sub_ranges: n_sub x (indexStart, indexCount).
+// mode 0: MeshSplitter::CreateChunks(mesh) (local chunks);  mode 1: a RayTracedMesh without cached chunks and with that mesh as
+// meshFilter.sharedMesh, posed by transform10 = position(3) rotation xyzw(4) lossyScale(3): GetSubMeshes() (world chunks);
+// mode 2: Split(CreateSubMeshFromTriangles(the mesh's triangles in index order, seed, 0)) with seed = seed3 (the restatement tests
+// search the seed vertex the reference must have had).  The chunks stay in a thread-local result until the next call.
+namespace { thread_local std::vector<rthost::MeshChunk> g_chunks; }
+
+int rth_split_mesh(const float* verts, const float* normals, int n_verts, const int* indices, int n_indices,
+                   const int* sub_ranges, int n_sub, int mode, const float* transform10, const float* seed3, int enforce_limit)
+{
+    try {
+        rthost::Mesh m;
+        m.vertices.resize((size_t)n_verts); m.normals.resize((size_t)n_verts);
+        for (int i = 0; i < n_verts; ++i) {
+            m.vertices[(size_t)i] = { verts[3 * i], verts[3 * i + 1], verts[3 * i + 2] };
+            m.normals[(size_t)i] = { normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] };
+        }
+        m.triangles.assign(indices, indices + n_indices);
+        for (int i = 0; i < n_sub; ++i) m.subMeshes.push_back({ sub_ranges[2 * i], sub_ranges[2 * i + 1] });
+        if (mode == 0) g_chunks = rthost::MeshSplitter::CreateChunks(m);
+        else if (mode == 1) {
+            rthost::RayTracedMesh rm;
+            rm.sharedMesh = &m; rm.enforceTriangleLimit = enforce_limit != 0;
+            rm.transform.position = { transform10[0], transform10[1], transform10[2] };
+            rm.transform.rotation = { transform10[3], transform10[4], transform10[5], transform10[6] };
+            rm.transform.lossyScale = { transform10[7], transform10[8], transform10[9] };
+            g_chunks = rm.GetSubMeshes();
+        } else {
+            rthost::MeshChunk whole = rthost::MeshSplitter::CreateSubMesh(m, 0, n_indices, 0);
+            whole = rthost::MeshSplitter::CreateSubMeshFromTriangles(whole.triangles, { seed3[0], seed3[1], seed3[2] }, 0);
+            g_chunks.clear();
+            rthost::MeshSplitter::Split(whole, g_chunks);
+        }
+        return (int)g_chunks.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// tri_counts[n], sub_mesh[n], bounds[n*6] = centre xyz, size xyz; then rth_split_triangles copies all chunks' triangles back to back
+void rth_split_info(int* tri_counts, int* sub_mesh, float* bounds)
+{
+    for (size_t i = 0; i < g_chunks.size(); ++i) {
+        const rthost::MeshChunk& c = g_chunks[i];
+        tri_counts[i] = (int)c.triangles.size(); sub_mesh[i] = c.subMeshIndex;
+        bounds[6 * i] = c.bounds.center.x; bounds[6 * i + 1] = c.bounds.center.y; bounds[6 * i + 2] = c.bounds.center.z;
+        bounds[6 * i + 3] = c.bounds.size.x; bounds[6 * i + 4] = c.bounds.size.y; bounds[6 * i + 5] = c.bounds.size.z;
+    }
+}
+void rth_split_triangles(rt_triangle* out)
+{
+    for (const rthost::MeshChunk& c : g_chunks) {
+        if (!c.triangles.empty()) std::memcpy(out, c.triangles.data(), c.triangles.size() * sizeof(rt_triangle));
+        out += c.triangles.size();
+    }
+}
+
 } // extern "C"

@@ -24,8 +24,38 @@ def load_host_library():
         L.rth_build.argtypes = [c_void_p, POINTER(c_int)]
         L.rth_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.rth_render.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
+        L.rth_split_mesh.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]
+        L.rth_split_info.argtypes = [c_void_p, c_void_p, c_void_p]
+        L.rth_split_triangles.argtypes = [c_void_p]
         _lib = L
     return _lib
+
+
+def cpp_split_mesh(vertices, normals, indices, sub_ranges, mode=0, transform=None, seed=None, enforce_limit=True):
+    """The compiled host's MeshSplitter::CreateChunks (mode 0), RayTracedMesh::GetSubMeshes on a mesh without cached chunks
+    (mode 1, transform = position(3) + rotation xyzw(4) + lossyScale(3)) or Split from an explicit seed vertex (mode 2).
+    Returns [(TRIANGLE[n], centre[3], size[3], subMeshIndex)]."""
+    L = load_host_library()
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.int32).reshape(-1)
+    sub = np.ascontiguousarray(sub_ranges, np.int32).reshape(-1, 2)
+    tf = np.ascontiguousarray(transform if transform is not None else [0, 0, 0, 0, 0, 0, 1, 1, 1, 1], np.float32)
+    sd = np.ascontiguousarray(seed if seed is not None else [0, 0, 0], np.float32)
+    nc = L.rth_split_mesh(v.ctypes.data_as(c_void_p), n.ctypes.data_as(c_void_p), len(v), idx.ctypes.data_as(c_void_p), len(idx),
+                          sub.ctypes.data_as(c_void_p), len(sub), mode, tf.ctypes.data_as(c_void_p), sd.ctypes.data_as(c_void_p),
+                          1 if enforce_limit else 0)
+    if nc < 0:
+        raise RtError(L.rth_last_error().decode())
+    counts, subm, bounds = np.zeros(nc, np.int32), np.zeros(nc, np.int32), np.zeros((nc, 6), np.float32)
+    L.rth_split_info(counts.ctypes.data_as(c_void_p), subm.ctypes.data_as(c_void_p), bounds.ctypes.data_as(c_void_p))
+    tris = np.zeros(int(counts.sum()), TRIANGLE)
+    L.rth_split_triangles(tris.ctypes.data_as(c_void_p))
+    out, at = [], 0
+    for i in range(nc):
+        out.append((tris[at:at + counts[i]], bounds[i, :3].copy(), bounds[i, 3:].copy(), int(subm[i])))
+        at += counts[i]
+    return out
 
 
 class CppScene:
