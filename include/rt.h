@@ -256,6 +256,35 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * Either destination may be NULL.  Tests check that every f16 box contains its f32 box.                                 */
 int rt_read_bvh(rt_ctx* ctx, void* nodes_f32, void* nodes_f16, size_t n_nodes);
 
+/* ---- several GPUs of one node behind one handle ---------------------------------------------------------------------
+ * The reference renders on one GPU; its path shards into independent pixels (seed = global pixel index + Frame * 719393,
+ * RayTracing.shader:360-362; Accumulate.shader is per pixel), so the frame tiles across devices by rows.  An rt_multi owns one
+ * rt_ctx per entry of `devices` (a device may appear more than once: several contexts on one GPU, which is how the single-GPU
+ * tests exercise this path).  Scene and uniforms are replicated (rt_multi_set_params / rt_multi_upload_* replace the same
+ * RayTracingManager calls as their single-device forms); context i renders the 8-row bands b with b % N == i
+ * (rt_set_bands(i, N)); rt_multi_render runs the N contexts concurrently for all n_frames and ends with the path's only
+ * exchange: one gather of the accumulated strips to the first device (N - 1 peer copies over xGMI + a row scatter).  The
+ * assembled image is bit-identical to a single-context render (tested).  rt_multi_context gives the per-device context for
+ * options, statistics and per-strip read-back.                                                                         */
+typedef struct rt_multi rt_multi;
+rt_multi*   rt_multi_create(const int* devices, int n_devices);
+void        rt_multi_destroy(rt_multi* m);
+const char* rt_multi_last_error(const rt_multi* m);
+int         rt_multi_count(const rt_multi* m);
+rt_ctx*     rt_multi_context(rt_multi* m, int i);
+int rt_multi_set_params      (rt_multi* m, const rt_params* params);
+int rt_multi_upload_spheres  (rt_multi* m, const rt_sphere*   spheres,  int n);
+int rt_multi_upload_triangles(rt_multi* m, const rt_triangle* tris,     int n);
+int rt_multi_upload_meshinfo (rt_multi* m, const rt_meshinfo* meshinfo, int n);
+int rt_multi_set_option      (rt_multi* m, const char* name, int value);
+int rt_multi_reset_accum     (rt_multi* m);
+int rt_multi_render          (rt_multi* m, int first_frame, int n_frames);
+/* the assembled resultTexture: height*width*4 floats, row 0 = bottom */
+int rt_multi_read_accum      (rt_multi* m, float* rgba, size_t n_floats);
+/* rays and work counters summed over the contexts, kernel times = the slowest context's; gather_ms (may be NULL) = HIP-event
+ * time of the last gather on the first device                                                                           */
+int rt_multi_get_stats       (rt_multi* m, rt_stats* out, double* gather_ms);
+
 /* ABI self-description for binding generators / tests. */
 int rt_abi_version(void);
 int rt_sizeof(const char* struct_name);   /* "rt_material" | "rt_sphere" | "rt_triangle" | "rt_meshinfo" | "rt_params" | "rt_stats" | "rt_mesh_transform" | "rt_local_chunk" */

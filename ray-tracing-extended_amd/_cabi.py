@@ -57,6 +57,9 @@ SYMBOLS = [
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
     "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry", "rt_read_display",
     "rt_read_bvh", "rt_write_accum",
+    "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_count", "rt_multi_context", "rt_multi_set_params",
+    "rt_multi_upload_spheres", "rt_multi_upload_triangles", "rt_multi_upload_meshinfo", "rt_multi_set_option", "rt_multi_reset_accum",
+    "rt_multi_render", "rt_multi_read_accum", "rt_multi_get_stats",
 ]
 
 _lib = None
@@ -105,9 +108,27 @@ def load_library() -> ctypes.CDLL:
     lib.rt_write_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t, c_int]
     lib.rt_abi_version.restype = c_int
     lib.rt_sizeof.argtypes = [c_char_p]
+    lib.rt_multi_create.restype = c_void_p
+    lib.rt_multi_create.argtypes = [POINTER(c_int), c_int]
+    lib.rt_multi_destroy.restype = None
+    lib.rt_multi_destroy.argtypes = [c_void_p]
+    lib.rt_multi_last_error.restype = c_char_p
+    lib.rt_multi_last_error.argtypes = [c_void_p]
+    lib.rt_multi_count.argtypes = [c_void_p]
+    lib.rt_multi_context.restype = c_void_p
+    lib.rt_multi_context.argtypes = [c_void_p, c_int]
+    lib.rt_multi_set_params.argtypes = [c_void_p, c_void_p]
+    for n in ("rt_multi_upload_spheres", "rt_multi_upload_triangles", "rt_multi_upload_meshinfo"):
+        getattr(lib, n).argtypes = [c_void_p, c_void_p, c_int]
+    lib.rt_multi_set_option.argtypes = [c_void_p, c_char_p, c_int]
+    lib.rt_multi_reset_accum.argtypes = [c_void_p]
+    lib.rt_multi_render.argtypes = [c_void_p, c_int, c_int]
+    lib.rt_multi_read_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t]
+    lib.rt_multi_get_stats.argtypes = [c_void_p, c_void_p, c_void_p]
     for n in SYMBOLS:
         f = getattr(lib, n)
-        if f.restype is None or n in ("rt_create", "rt_last_error", "rt_destroy"):
+        if f.restype is None or n in ("rt_create", "rt_last_error", "rt_destroy", "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error",
+                                      "rt_multi_context"):
             continue
         f.restype = c_int
     for name, dt in (("rt_material", MATERIAL), ("rt_sphere", SPHERE), ("rt_triangle", TRIANGLE),
@@ -266,3 +287,75 @@ class Tracer:
         s = np.zeros((), STATS)
         self._check(self._lib.rt_get_stats(self._ctx, s.ctypes.data_as(c_void_p)), "rt_get_stats")
         return {k: (s[k].item() if s[k].ndim == 0 else s[k].tolist()) for k in STATS.names}
+
+
+class MultiTracer:
+    """One rt_multi: N contexts (one per entry of `devices`; a device may repeat), interleaved 8-row bands, one gather to the
+    first device at the end of render()."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        arr = (c_int * len(devices))(*devices)
+        self._m = self._lib.rt_multi_create(arr, len(devices))
+        if not self._m:
+            raise RtError("rt_multi_create failed: " + (self._lib.rt_multi_last_error(None) or b"").decode())
+        self._shape = None
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.rt_multi_destroy(self._m)
+            self._m = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): " + (self._lib.rt_multi_last_error(self._m) or b"").decode())
+
+    def count(self) -> int:
+        return self._lib.rt_multi_count(self._m)
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, dtype=PARAMS).reshape(())
+        self._shape = (int(p["height"]), int(p["width"]))
+        self._check(self._lib.rt_multi_set_params(self._m, p.ctypes.data_as(c_void_p)), "rt_multi_set_params")
+
+    def upload(self, spheres=None, triangles=None, meshinfo=None):
+        for arr, dt, fn in ((spheres, SPHERE, "rt_multi_upload_spheres"), (triangles, TRIANGLE, "rt_multi_upload_triangles"),
+                            (meshinfo, MESHINFO, "rt_multi_upload_meshinfo")):
+            if arr is not None:
+                a, ptr, n = _as_buffer(arr, dt)
+                self._check(getattr(self._lib, fn)(self._m, ptr, n), fn)
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.rt_multi_set_option(self._m, name.encode(), int(value)), f"rt_multi_set_option({name})")
+
+    def reset_accum(self):
+        self._check(self._lib.rt_multi_reset_accum(self._m), "rt_multi_reset_accum")
+
+    def render(self, first_frame: int, n_frames: int):
+        self._check(self._lib.rt_multi_render(self._m, first_frame, n_frames), "rt_multi_render")
+
+    def read_accum(self) -> np.ndarray:
+        H, W = self._shape
+        out = np.empty((H, W, 4), np.float32)
+        self._check(self._lib.rt_multi_read_accum(self._m, out.ctypes.data_as(POINTER(c_float)), out.size), "rt_multi_read_accum")
+        return out
+
+    def stats(self) -> dict:
+        s = np.zeros((), STATS)
+        g = ctypes.c_double(0.0)
+        self._check(self._lib.rt_multi_get_stats(self._m, s.ctypes.data_as(c_void_p), ctypes.byref(g)), "rt_multi_get_stats")
+        d = {k: (s[k].item() if s[k].ndim == 0 else s[k].tolist()) for k in STATS.names}
+        d["gatherMs"] = g.value
+        return d

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_kernels.hpp"
@@ -1019,6 +1020,188 @@ int rt_get_stats(rt_ctx* c, rt_stats* out)
     if (!c) return -1;
     if (!out) return fail(c, -2, "null stats");
     *out = c->stats;
+    return 0;
+}
+
+} // extern "C"
+
+// ---- several devices behind one handle: frames tile across the GPUs of a node -------------------------------------------
+// The path shards into independent pixels (seeds use global pixel coordinates, RayTracing.shader:360-362; accumulation is per
+// pixel), so every device holds the whole scene, renders the 8-row bands b with b % N == its rank for all frames, and one
+// gather at the end of rt_multi_render brings the strips to the first device: N - 1 peer copies (xGMI point-to-point, each over
+// its own link on a fully connected node) and a row scatter.  No other exchange exists on the path.
+struct rt_multi {
+    std::vector<rt_ctx*> ctx;
+    std::string err;
+    int width = 0, height = 0;
+    bool have_params = false;
+    DevBuf<float4> d_image, d_staging;          // on the first context's device: the assembled image, the incoming strips
+    int max_rows = 0;
+    double lastGatherMs = 0;
+};
+
+namespace {
+
+int mfail(rt_multi* m, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (m) m->err = buf; else g_create_error = buf;
+    return code;
+}
+
+template <class Fn> int for_each_ctx(rt_multi* m, const char* what, Fn f)
+{
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        const int r = f(m->ctx[i]);
+        if (r) return mfail(m, r, "%s on context %zu: %s", what, i, rt_last_error(m->ctx[i]));
+    }
+    return 0;
+}
+
+// rows of rank r (bands r, r + N, ...) from its strip to their places in the image
+__global__ __launch_bounds__(256) void k_scatter_bands(const float4* __restrict__ strip, float4* __restrict__ image, int W, int H, int rank, int N)
+{
+    const size_t n = (size_t)W * 8;
+    int local_band = blockIdx.y;
+    const int y0 = (rank + local_band * N) * 8;
+    if (y0 >= H) return;
+    const int rows = min(8, H - y0);
+    const float4* src = strip + (size_t)local_band * n;
+    float4* dst = image + (size_t)y0 * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)rows * W; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+} // namespace
+
+extern "C" {
+
+rt_multi* rt_multi_create(const int* devices, int n_devices)
+{
+    if (n_devices < 1 || !devices) { mfail(nullptr, -1, "rt_multi_create: no devices given"); return nullptr; }
+    rt_multi* m = new rt_multi();
+    for (int i = 0; i < n_devices; ++i) {
+        rt_ctx* c = rt_create(devices[i]);
+        if (!c) { const std::string e = g_create_error; rt_multi_destroy(m); g_create_error = e; return nullptr; }
+        m->ctx.push_back(c);
+    }
+    // direct peer copies into the first device where the hardware allows it (errors here only mean a slower copy path)
+    (void)hipSetDevice(m->ctx[0]->device);
+    for (int i = 1; i < n_devices; ++i)
+        if (m->ctx[i]->device != m->ctx[0]->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->ctx[0]->device, m->ctx[i]->device) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(m->ctx[i]->device, 0);
+            (void)hipGetLastError();
+        }
+    return m;
+}
+
+void rt_multi_destroy(rt_multi* m)
+{
+    if (!m) return;
+    if (!m->ctx.empty()) { (void)hipSetDevice(m->ctx[0]->device); m->d_image.release(); m->d_staging.release(); }
+    for (rt_ctx* c : m->ctx) rt_destroy(c);
+    delete m;
+}
+
+const char* rt_multi_last_error(const rt_multi* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+int rt_multi_count(const rt_multi* m) { return m ? (int)m->ctx.size() : 0; }
+rt_ctx* rt_multi_context(rt_multi* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+
+int rt_multi_set_params(rt_multi* m, const rt_params* p)
+{
+    if (!m) return -1;
+    if (!p) return mfail(m, -2, "null params");
+    const int N = (int)m->ctx.size();
+    for (int i = 0; i < N; ++i) {
+        int r = rt_set_params(m->ctx[i], p);
+        if (!r) r = rt_set_bands(m->ctx[i], i, N);
+        if (r) return mfail(m, r, "rt_set_params on context %d: %s", i, rt_last_error(m->ctx[i]));
+    }
+    m->width = p->width; m->height = p->height; m->have_params = true;
+    return 0;
+}
+int rt_multi_upload_spheres(rt_multi* m, const rt_sphere* s, int n) { return m ? for_each_ctx(m, "rt_upload_spheres", [&](rt_ctx* c) { return rt_upload_spheres(c, s, n); }) : -1; }
+int rt_multi_upload_triangles(rt_multi* m, const rt_triangle* t, int n) { return m ? for_each_ctx(m, "rt_upload_triangles", [&](rt_ctx* c) { return rt_upload_triangles(c, t, n); }) : -1; }
+int rt_multi_upload_meshinfo(rt_multi* m, const rt_meshinfo* mi, int n) { return m ? for_each_ctx(m, "rt_upload_meshinfo", [&](rt_ctx* c) { return rt_upload_meshinfo(c, mi, n); }) : -1; }
+int rt_multi_set_option(rt_multi* m, const char* name, int value) { return m ? for_each_ctx(m, "rt_set_option", [&](rt_ctx* c) { return rt_set_option(c, name, value); }) : -1; }
+int rt_multi_reset_accum(rt_multi* m) { return m ? for_each_ctx(m, "rt_reset_accum", [&](rt_ctx* c) { return rt_reset_accum(c); }) : -1; }
+
+int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
+{
+    if (!m) return -1;
+    if (!m->have_params) return mfail(m, -2, "rt_multi_set_params has not been called");
+    const int N = (int)m->ctx.size();
+    // every device renders its bands for all frames, concurrently: one host thread per context (a context is single-threaded,
+    // the contexts are independent)
+    std::vector<int> rc(N, 0);
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < N; ++i) th.emplace_back([&, i]() { rc[i] = rt_render(m->ctx[i], first_frame, n_frames); });
+        rc[0] = rt_render(m->ctx[0], first_frame, n_frames);
+        for (std::thread& t : th) t.join();
+    }
+    for (int i = 0; i < N; ++i) if (rc[i]) return mfail(m, rc[i], "rt_render on context %d: %s", i, rt_last_error(m->ctx[i]));
+    // ---- the one gather: strips -> first device, rows to their places
+    rt_ctx* root = m->ctx[0];
+    const int W = m->width, H = m->height;
+    if ((size_t)W * H == 0) return 0;
+    RT_HIP(root, hipSetDevice(root->device));
+    int max_rows = 0;
+    for (rt_ctx* c : m->ctx) max_rows = std::max(max_rows, c->target_rows);
+    RT_HIP(root, m->d_image.ensure((size_t)W * H));
+    RT_HIP(root, m->d_staging.ensure((size_t)W * max_rows * (size_t)std::max(1, N - 1)));
+    RT_HIP(root, hipEventRecord(root->evg0, root->stream));
+    for (int i = 1; i < N; ++i) {
+        rt_ctx* c = m->ctx[i];
+        if (c->target_pixels == 0) continue;
+        float4* dst = m->d_staging.p + (size_t)(i - 1) * W * max_rows;
+        if (c->device == root->device) RT_HIP(root, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, root->stream));
+        else RT_HIP(root, hipMemcpyPeerAsync(dst, root->device, c->d_accum.p, c->device, c->target_pixels * sizeof(float4), root->stream));
+    }
+    for (int i = 0; i < N; ++i) {
+        rt_ctx* c = m->ctx[i];
+        if (c->target_pixels == 0) continue;
+        const float4* src = i == 0 ? c->d_accum.p : m->d_staging.p + (size_t)(i - 1) * W * max_rows;
+        const int bands = (c->target_rows + 7) / 8;
+        hipLaunchKernelGGL(k_scatter_bands, dim3(std::max(1, std::min(64, (W * 8 + 255) / 256)), bands), dim3(256), 0, root->stream, src, m->d_image.p, W, H, i, N);
+    }
+    RT_HIP(root, hipGetLastError());
+    RT_HIP(root, hipEventRecord(root->evg1, root->stream));
+    RT_HIP(root, hipStreamSynchronize(root->stream));
+    float ms = 0.f;
+    RT_HIP(root, hipEventElapsedTime(&ms, root->evg0, root->evg1));
+    m->lastGatherMs = ms;
+    return 0;
+}
+
+int rt_multi_read_accum(rt_multi* m, float* rgba, size_t n_floats)
+{
+    if (!m) return -1;
+    if (!rgba && n_floats) return mfail(m, -2, "null destination");
+    if (n_floats != (size_t)m->width * m->height * 4) return mfail(m, -2, "expected %zu floats (height*width*4), got %zu", (size_t)m->width * m->height * 4, n_floats);
+    if (!n_floats) return 0;
+    if (!m->d_image.p) return mfail(m, -2, "nothing rendered yet");
+    rt_ctx* root = m->ctx[0];
+    RT_HIP(root, hipSetDevice(root->device));
+    RT_HIP(root, hipMemcpy(rgba, m->d_image.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rt_multi_get_stats(rt_multi* m, rt_stats* out, double* gather_ms)
+{
+    if (!m) return -1;
+    if (!out) return mfail(m, -2, "null stats");
+    rt_stats sum = m->ctx[0]->stats;
+    for (size_t i = 1; i < m->ctx.size(); ++i) {
+        const rt_stats& s = m->ctx[i]->stats;
+        sum.rays += s.rays; sum.sphereTests += s.sphereTests; sum.nodeVisits += s.nodeVisits; sum.triTests += s.triTests; sum.hits += s.hits;
+        for (int k = 0; k < 5; ++k) { sum.phaseLanes[k] += s.phaseLanes[k]; sum.phaseExecs[k] += s.phaseExecs[k]; }
+        sum.lastKernelMs = std::max(sum.lastKernelMs, s.lastKernelMs); sum.totalKernelMs = std::max(sum.totalKernelMs, s.totalKernelMs);
+    }
+    *out = sum;
+    if (gather_ms) *gather_ms = m->lastGatherMs;
     return 0;
 }
 

@@ -1,0 +1,58 @@
+"""Multi-device path on the one GPU the test box has: N contexts on device 0 behind one rt_multi (the in-library row-band
+decomposition + gather of include/rt.h), and two gloo ranks that each drive a real context."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bitwise, run_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n,size,frames", [(1, (64, 40), 3), (2, (104, 75), 5), (3, (93, 61), 4), (5, (40, 200), 16), (8, (64, 36), 2)])
+def test_n_contexts_behind_rt_multi_equal_the_undivided_image(rtx, oracle, tracer, n, size, frames):
+    """rt_multi with n contexts on device 0: interleaved bands, concurrent renders, one gather — bit-identical to one context
+    rendering the whole image and to the oracle; rays add up.  (8 contexts on 36 rows: three of them own no band at all.)"""
+    b = rtx.scenes.mesh_test_scene(*size).build_buffers()
+    params, spheres, tris, infos = b
+    with rtx.MultiTracer([0] * n) as mt:
+        assert mt.count() == n
+        mt.set_option("kernel", 1)
+        mt.set_params(params)
+        mt.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+        mt.render(1, frames)
+        got = mt.read_accum()
+        st = mt.stats()
+        mt.reset_accum()
+        mt.render(1, frames)                    # a second render over the reset state gives the same image
+        again = mt.read_accum()
+    ref, _ = run_gpu(tracer, b, 1, frames, kernel=1)
+    want, _, cnt = oracle.render(*b, 1, frames)
+    assert_bitwise(got, ref, f"rt_multi x{n} vs one context")
+    assert_bitwise(got, want, f"rt_multi x{n} vs oracle")
+    assert_bitwise(again, want, f"rt_multi x{n}, second render")
+    assert st["rays"] == cnt["rays"]
+    assert st["gatherMs"] >= 0.0
+
+
+def test_rt_multi_error_paths(rtx):
+    with pytest.raises(rtx.RtError):
+        rtx.MultiTracer([99])
+    with rtx.MultiTracer([0, 0]) as mt:
+        with pytest.raises(rtx.RtError):
+            mt.render(0, 1)                     # no params yet
+        with pytest.raises(rtx.RtError):
+            mt.set_option("no_such_option", 1)
+
+
+def test_two_gloo_ranks_render_their_bands_on_the_gpu():
+    """bench.py's N > 1 shape with real kernels: two processes, each with its own rt_ctx on GPU 0, bands + one gather (gloo)."""
+    env = dict(os.environ, RTX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "tests", "gloo_gpu_band_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GLOO_GPU_BANDS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
