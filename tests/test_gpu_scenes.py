@@ -184,6 +184,68 @@ def test_4k_frame_vs_oracle_brute_mode(rtx, oracle, tracer):
     _full_frame_vs_oracle(oracle, tracer, m, "config4 4K vs oracle", mode=1)
 
 
+def test_4k_frame_vs_oracle_flat_chunks_mode(rtx, oracle, tracer):
+    """configs[3] (3840x2160, 12 bounces), 1 ray per pixel, the reference's literal FLAT_CHUNKS semantics (a triangle counts only if
+    its chunk's RayBoundingBox passes), whole frame; the ray count is the oracle's."""
+    m = rtx.scenes.config4()
+    m.numRaysPerPixel = 1
+    rays, cnt = _full_frame_vs_oracle(oracle, tracer, m, "config4 4K FLAT_CHUNKS vs oracle", mode=0, frame=2)
+    assert rays == cnt["rays"] > 8_000_000
+
+
+def test_config2_full_size_vs_oracle(rtx, oracle, tracer):
+    """configs[1] exactly as BASELINE names it: 12 spheres, 1920x1080, 64 rays per pixel, 8 bounces — a whole frame (~3.4e8 rays)
+    through the automatic kernel choice, every pixel and the ray count against the oracle's literal loop."""
+    m = rtx.scenes.config2()
+    assert (m.numRaysPerPixel, m.maxBounceCount, m.width, m.height) == (64, 8, 1920, 1080)
+    b = m.build_buffers()
+    _, got = run_gpu(tracer, b, 1, 1, kernel=-1)
+    rays = tracer.stats()["rays"]
+    want, cnt = oracle.render_frame(*b, 1)
+    assert_bitwise(got, want, "config2 1080p x64 vs oracle")
+    assert rays == cnt["rays"] > 300_000_000
+
+
+def test_million_triangle_full_hd_vs_oracle(rtx, oracle, tracer):
+    """configs[4] at its own resolution: 1,004,364 triangles, depth of field, 1920x1080, 1 ray per pixel, whole frame."""
+    m = rtx.scenes.config5()
+    m.numRaysPerPixel = 1
+    rays, cnt = _full_frame_vs_oracle(oracle, tracer, m, "config5 1080p vs oracle", frame=1)
+    assert rays == cnt["rays"]
+
+
+def test_headline_job_two_frames_accumulated_vs_oracle(rtx, oracle, tracer):
+    """A two-frame cut of tools/validate_headline.py: frames 0 and 1 of the headline job (1920x1080, 100,440 triangles, 64 rays per
+    pixel, 8 bounces) traced in ONE launch and accumulated — resultTexture and ray count equal the oracle's (~4.9e8 rays)."""
+    b = rtx.scenes.config3().build_buffers()
+    acc, _ = run_gpu(tracer, b, 0, 2, kernel=-1)
+    rays = tracer.stats()["rays"]
+    want = None
+    total = 0
+    for f in range(2):
+        cur, cnt = oracle.render_frame(*b, f, accel=True)
+        if want is None:
+            want = np.zeros_like(cur)
+        oracle.accumulate(want, cur, f)
+        total += cnt["rays"]
+    assert_bitwise(acc, want, "headline job, frames 0-1 accumulated")
+    assert rays == total > 400_000_000
+
+
+def test_sixteen_interleaved_frames_full_hd_vs_oracle(rtx, oracle, tracer):
+    """The launch shape of the benchmark (one launch of 16 frames, a wave = 2x2 pixels x 16 frames) at 1920x1080 on the headline
+    scene with 1 ray per pixel: the accumulated image of all 16 frames equals the oracle's."""
+    m = rtx.scenes.config3()
+    m.numRaysPerPixel = 1
+    b = m.build_buffers()
+    acc, _ = run_gpu(tracer, b, 0, 16, kernel=1)
+    st = tracer.stats()
+    assert st["lastFramesPerLaunch"] == 16 and st["lastFramesInterleaved"] == 16
+    want, _, cnt = oracle.render(*b, 0, 16, accel=True)
+    assert_bitwise(acc, want, "16 interleaved frames, 1080p")
+    assert st["rays"] == cnt["rays"]
+
+
 def test_render_scene_tool_writes_what_the_tracer_holds(rtx, tracer, tmp_path):
     """tools/render_scene.py (scene file -> OnRenderImage -> PNG / EXR): the EXR equals the accumulated resultTexture of the
     same render through the API, bit for bit; the PNG decodes to the display step's bytes."""
