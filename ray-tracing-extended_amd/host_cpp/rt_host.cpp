@@ -334,4 +334,38 @@ void RayTracingManager::OnRenderImage(rt_ctx* ctx, int frames, std::vector<float
     }
 }
 
+static void mcheck(rt_multi* m, int rc, const char* what)
+{
+    if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + rt_multi_last_error(m));
+}
+
+void RayTracingManager::InitFrame(rt_multi* m)
+{
+    SceneBuffers b = BuildBuffers();
+    mcheck(m, rt_multi_set_params(m, &b.params), "rt_multi_set_params");
+    if (!uploaded_) {
+        mcheck(m, rt_multi_upload_spheres(m, b.spheres.data(), (int)b.spheres.size()), "rt_multi_upload_spheres");
+        mcheck(m, rt_multi_upload_triangles(m, b.triangles.data(), (int)b.triangles.size()), "rt_multi_upload_triangles");
+        mcheck(m, rt_multi_upload_meshinfo(m, b.meshInfo.data(), (int)b.meshInfo.size()), "rt_multi_upload_meshinfo");
+        uploaded_ = true;
+    }
+}
+
+void RayTracingManager::Start(rt_multi* m)
+{
+    numRenderedFrames = 0;
+    mcheck(m, rt_multi_reset_accum(m), "rt_multi_reset_accum");
+}
+
+void RayTracingManager::OnRenderImage(rt_multi* m, int frames, std::vector<float>* resultTexture)
+{
+    InitFrame(m);
+    mcheck(m, rt_multi_render(m, numRenderedFrames, frames), "rt_multi_render");
+    numRenderedFrames += frames;
+    if (resultTexture) {
+        resultTexture->resize((size_t)width * height * 4);
+        mcheck(m, rt_multi_read_accum(m, resultTexture->data(), resultTexture->size()), "rt_multi_read_accum");
+    }
+}
+
 } // namespace rthost

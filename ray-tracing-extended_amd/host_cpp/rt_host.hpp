@@ -125,6 +125,11 @@ public:
     void InitFrame(rt_ctx* ctx);
     void OnRenderImage(rt_ctx* ctx, int frames, std::vector<float>* resultTexture = nullptr);
     void Start(rt_ctx* ctx);                                                     // :43-46
+    // The same through an rt_multi: the frame tiles across the GPUs of the node (interleaved row bands inside the library, one
+    // gather at the end of the call); resultTexture is the assembled full image.
+    void InitFrame(rt_multi* multi);
+    void OnRenderImage(rt_multi* multi, int frames, std::vector<float>* resultTexture = nullptr);
+    void Start(rt_multi* multi);
 private:
     bool uploaded_ = false;
 };

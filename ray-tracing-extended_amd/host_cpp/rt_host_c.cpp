@@ -65,6 +65,24 @@ int rth_render(void* hp, int device, int frames, float* rgba)
     return rc;
 }
 
+// The same scene through an rt_multi of n_contexts contexts (devices[i] each): RayTracingManager::OnRenderImage(rt_multi*, ...).
+int rth_render_multi(void* hp, const int* devices, int n_contexts, int frames, float* rgba)
+{
+    auto* h = static_cast<Handle*>(hp);
+    rt_multi* m = rt_multi_create(devices, n_contexts);
+    if (!m) { g_err = rt_multi_last_error(nullptr); return -1; }
+    int rc = 0;
+    try {
+        std::vector<float> out;
+        rthost::RayTracingManager mgr = h->mgr;          // a fresh manager state (nothing uploaded yet) for this handle
+        mgr.Start(m);
+        mgr.OnRenderImage(m, frames, &out);
+        std::memcpy(rgba, out.data(), out.size() * sizeof(float));
+    } catch (const std::exception& e) { g_err = e.what(); rc = -1; }
+    rt_multi_destroy(m);
+    return rc;
+}
+
 // ---- MeshSplitter / RayTracedMesh.GetSubMeshes through plain arrays (tests) --------------------------------------------
 // verts / normals: n_verts x 3 floats; indices: the index buffer; sub_ranges: n_sub x (indexStart, indexCount).
 // mode 0: MeshSplitter::CreateChunks(mesh) (local chunks);  mode 1: a RayTracedMesh without cached chunks and with that mesh as

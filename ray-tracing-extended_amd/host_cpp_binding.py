@@ -24,11 +24,20 @@ def load_host_library():
         L.rth_build.argtypes = [c_void_p, POINTER(c_int)]
         L.rth_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.rth_render.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
+        L.rth_render_multi.argtypes = [c_void_p, POINTER(c_int), c_int, c_int, POINTER(c_float)]
         L.rth_split_mesh.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]
         L.rth_split_info.argtypes = [c_void_p, c_void_p, c_void_p]
         L.rth_split_triangles.argtypes = [c_void_p]
         _lib = L
     return _lib
+
+    def render_multi(self, frames: int, devices) -> np.ndarray:
+        """RayTracingManager::OnRenderImage(rt_multi*, frames): the frame tiled over len(devices) contexts; returns [H, W, 4]."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        arr = (c_int * len(devices))(*devices)
+        if self._L.rth_render_multi(self._h, arr, len(devices), frames, out.ctypes.data_as(POINTER(c_float))):
+            raise RtError("OnRenderImage(rt_multi): " + self._L.rth_last_error().decode())
+        return out
 
 
 def cpp_split_mesh(vertices, normals, indices, sub_ranges, mode=0, transform=None, seed=None, enforce_limit=True):

@@ -85,8 +85,10 @@ def test_cpp_manager_renders_the_same_image(rtx, tracer, tmp_path):
     want, _ = run_gpu(tracer, mgr.build_buffers(), 0, 2)
     cpp = CppScene(path, 96, 64)
     got = cpp.render(2)
+    got3 = cpp.render_multi(2, [0, 0, 0])           # the same manager through an rt_multi of three contexts on this GPU
     cpp.close()
     assert_bitwise(got, want, "C++ host")
+    assert_bitwise(got3, want, "C++ host through rt_multi x3")
 
 
 def test_config5_million_triangles_crop_vs_oracle(rtx, oracle, tracer):
