@@ -1,0 +1,513 @@
+// rt_bvh_gpu.hpp — BVH build on the device: the step the reference does not have at all (it loops over a flat chunk list,
+// RayTracing.shader:276-294, re-created on the CPU every frame: RayTracingManager.cs:135-164, TODO at RayTracedMesh.cs:37).
+//
+// World-space triangles (the reference's 72-byte layout, already on the device) -> BVH4 nodes + triangle order, without a host
+// round trip of the geometry:
+//   1. k_tri_bounds      scene bounds over triangle-box centroids + the largest |coordinate| (box padding), block reduce + atomics
+//   2. k_morton          63-bit Morton code of each triangle's box centre, sorted with hipcub::DeviceRadixSort (the one library call)
+//   3. PLOC              (Meister & Bittner, "Parallel Locally-Ordered Clustering for BVH Construction", TVCG 2018): clusters in
+//                        Morton order; every round each cluster finds, among its 2R neighbours in the array, the one whose
+//                        union box has the smallest area; mutual pairs merge into a new binary node; the array is compacted
+//                        in order (block-local scan, scan of the block totals, gather).  Rounds run until one cluster is left;
+//                        the last <= 512 clusters finish inside a single workgroup without further launches.
+//   4. collapse          breadth-first, one launch per level: a binary node becomes a 4-wide node by opening its larger internal
+//                        children; two sibling triangles form one leaf (the tracer's leaf size); children of one node are
+//                        allocated contiguously, levels are contiguous ranges (what the refit kernels need); child boxes get
+//                        the same padding as the host builder's (bvh.cpp pad_box)
+//   5. k_stack_need      bottom-up, one launch per level: the exact worst-case traversal stack depth
+// The hierarchy only prunes: whichever tree is built, the closest hit is decided by the reference's triangle arithmetic and the
+// visiting-rank tie-break, so images do not change (tested bitwise against the host builder's tree and the oracle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "bvh.hpp"
+
+namespace rtgb {
+
+constexpr int kMaxRadius = 64;          // PLOC search radius (neighbours looked at on each side): run-time, up to this
+constexpr int kPlocBlock = 512;         // clusters per workgroup and round
+constexpr int kCtrNodes = 0, kCtrNode4 = 1, kCtrOrder = 2, kCtrFrontier = 3, kCtrClusters = 4, kCtrBounds = 8;   // counter slots (uint32)
+
+// monotone float <-> uint map for atomicMin / atomicMax on floats
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ inline float ord2f(uint32_t o) { const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+struct Box3 { float lo[3], hi[3]; };
+
+__device__ __forceinline__ Box3 tri_box(const float* __restrict__ p)
+{
+    Box3 b;
+    for (int a = 0; a < 3; ++a) {
+        // fminf / fmaxf return the non-NaN operand: a NaN coordinate does not poison the box (as std::min / std::max in bvh.cpp)
+        b.lo[a] = __builtin_fminf(__builtin_fminf(p[a], p[3 + a]), p[6 + a]);
+        b.hi[a] = __builtin_fmaxf(__builtin_fmaxf(p[a], p[3 + a]), p[6 + a]);
+    }
+    return b;
+}
+
+__device__ __forceinline__ float union_half_area(float4 amin, float4 amax, float4 bmin, float4 bmax)
+{
+    const float dx = __builtin_fmaxf(amax.x, bmax.x) - __builtin_fminf(amin.x, bmin.x);
+    const float dy = __builtin_fmaxf(amax.y, bmax.y) - __builtin_fminf(amin.y, bmin.y);
+    const float dz = __builtin_fmaxf(amax.z, bmax.z) - __builtin_fminf(amin.z, bmin.z);
+    const float a = dx * dy + dy * dz + dz * dx;
+    return a == a ? a : __builtin_inff();            // (inf - inf, 0 * inf: never the better candidate)
+}
+__device__ __forceinline__ float half_area(float4 mn, float4 mx)
+{
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+    const float a = dx * dy + dy * dz + dz * dx;
+    return (dx >= 0.f && a == a) ? a : 0.f;
+}
+
+// ---- 1. scene bounds of the box centres, and the largest finite |coordinate| ------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_bounds(const float* __restrict__ tris, uint32_t nt, uint32_t* __restrict__ ctr)
+{
+    float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -lo[0], -lo[0], -lo[0] }, mag = 0.f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += gridDim.x * blockDim.x) {
+        const Box3 b = tri_box(tris + (size_t)i * 18);
+        for (int a = 0; a < 3; ++a) {
+            const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+            if (c > -3.0e38f && c < 3.0e38f) { lo[a] = __builtin_fminf(lo[a], c); hi[a] = __builtin_fmaxf(hi[a], c); }
+            const float m = __builtin_fmaxf(__builtin_fabsf(b.lo[a]), __builtin_fabsf(b.hi[a]));
+            if (m < 3.0e38f) mag = __builtin_fmaxf(mag, m);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int a = 0; a < 3; ++a) { lo[a] = __builtin_fminf(lo[a], __shfl_down(lo[a], off, 64)); hi[a] = __builtin_fmaxf(hi[a], __shfl_down(hi[a], off, 64)); }
+        mag = __builtin_fmaxf(mag, __shfl_down(mag, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int a = 0; a < 3; ++a) { atomicMin(&ctr[kCtrBounds + a], f2ord(lo[a])); atomicMax(&ctr[kCtrBounds + 3 + a], f2ord(hi[a])); }
+        atomicMax(&ctr[kCtrBounds + 6], f2ord(mag));
+    }
+}
+
+// ---- 2. Morton codes ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t spread21(uint32_t v)
+{
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_morton(const float* __restrict__ tris, uint32_t nt, const uint32_t* __restrict__ ctr,
+                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const Box3 b = tri_box(tris + (size_t)i * 18);
+    // one scale for the three axes (the scene's largest extent): cubic cells.  Normalising each axis by its own extent makes the
+    // cells of a flat scene (a 150 x 2 x 90 floor of chess sets) as flat as the scene, and Morton neighbours would then be the
+    // upper halves of pieces tens of units apart rather than the two halves of one piece (measured: 1.9x the tree area).
+    float ext = 0.f;
+    for (int a = 0; a < 3; ++a) ext = __builtin_fmaxf(ext, ord2f(ctr[kCtrBounds + 3 + a]) - ord2f(ctr[kCtrBounds + a]));
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const float lo = ord2f(ctr[kCtrBounds + a]);
+        const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+        float t = (ext > 0.f) ? (c - lo) / ext : 0.f;
+        t = (t == t) ? __builtin_fminf(__builtin_fmaxf(t, 0.f), 1.f) : 0.f;
+        q[a] = (uint32_t)(t * 2097151.0f);
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    ids[i] = i;
+}
+
+// leaves of the binary tree = triangles in Morton order; the first cluster array is 0 .. nt-1
+__global__ __launch_bounds__(256) void k_leaf_boxes(const float* __restrict__ tris, const uint32_t* __restrict__ ids, uint32_t nt,
+                                                    float4* __restrict__ bmin, float4* __restrict__ bmax, uint32_t* __restrict__ clusters)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const Box3 b = tri_box(tris + (size_t)ids[i] * 18);
+    bmin[i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
+    bmax[i] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
+    clusters[i] = i;
+}
+
+// ---- 3. PLOC --------------------------------------------------------------------------------------------------------------------
+// nearest neighbour of local element e inside [lo, hi) of the staged window: smallest union area, ties to the smaller index
+// (with that rule the globally cheapest pair is always mutual, so every round merges at least one pair)
+__device__ __forceinline__ int ploc_nearest(const float4* smin, const float4* smax, int e, int lo, int hi, int kRadius)
+{
+    float best = __builtin_inff(); int bj = -1;
+    const float4 amin = smin[e], amax = smax[e];
+    for (int j = max(lo, e - kRadius); j < min(hi, e + kRadius + 1); ++j) {
+        if (j == e) continue;
+        const float c = union_half_area(amin, amax, smin[j], smax[j]);
+        if (bj < 0 || c < best) { best = c; bj = j; }
+    }
+    return bj;
+}
+
+// One round over clusters [0, m): block b owns [b * kPlocBlock, ...), stages its range plus 2R on each side, finds the nearest
+// neighbours of its range plus R on each side (so both sides of a block boundary see the same decisions), merges the mutual
+// pairs it owns the lower element of, and writes its surviving clusters, compacted in order, to tmp[b * kPlocBlock ...].
+__global__ __launch_bounds__(kPlocBlock) void k_ploc_round(const uint32_t* __restrict__ cin, uint32_t m, uint32_t nt,
+                                                           float4* __restrict__ bmin, float4* __restrict__ bmax, int2* __restrict__ child,
+                                                           uint32_t* __restrict__ ctr, uint32_t* __restrict__ tmp, uint32_t* __restrict__ block_count,
+                                                           int kRadius)
+{
+    constexpr int WMAX = kPlocBlock + 4 * kMaxRadius;
+    const int W = kPlocBlock + 4 * kRadius;
+    __shared__ float4 smin[WMAX], smax[WMAX];
+    __shared__ uint32_t sid[WMAX];
+    __shared__ int snn[WMAX];
+    __shared__ uint32_t scan[kPlocBlock];
+    const int start = (int)(blockIdx.x * kPlocBlock);
+    const int w0 = start - 2 * kRadius;                     // global index of window slot 0
+    for (int s = threadIdx.x; s < W; s += kPlocBlock) {
+        const int g = w0 + s;
+        if (g >= 0 && g < (int)m) { const uint32_t id = cin[g]; sid[s] = id; smin[s] = bmin[id]; smax[s] = bmax[id]; }
+    }
+    __syncthreads();
+    const int lo = max(0, -w0), hi = min(W, (int)m - w0);   // valid window slots
+    for (int s = threadIdx.x; s < W; s += kPlocBlock) {
+        const int g = w0 + s;
+        snn[s] = (g >= start - kRadius && g < start + kPlocBlock + kRadius && s >= lo && s < hi) ? ploc_nearest(smin, smax, s, lo, hi, kRadius) : -1;
+    }
+    __syncthreads();
+    const int e = (int)threadIdx.x + 2 * kRadius, g = start + (int)threadIdx.x;
+    uint32_t keep = 0, value = 0;
+    if (g < (int)m) {
+        const int j = snn[e];
+        const bool mutual = j >= 0 && snn[j] == e;
+        if (mutual && e < j) {
+            const uint32_t node = nt + atomicAdd(&ctr[kCtrNodes], 1u);
+            const float4 amin = smin[e], amax = smax[e], cmin = smin[j], cmax = smax[j];
+            bmin[node] = make_float4(__builtin_fminf(amin.x, cmin.x), __builtin_fminf(amin.y, cmin.y), __builtin_fminf(amin.z, cmin.z), 0.f);
+            bmax[node] = make_float4(__builtin_fmaxf(amax.x, cmax.x), __builtin_fmaxf(amax.y, cmax.y), __builtin_fmaxf(amax.z, cmax.z), 0.f);
+            child[node] = make_int2((int)sid[e], (int)sid[j]);
+            keep = 1; value = node;
+        } else if (!mutual) { keep = 1; value = sid[e]; }
+    }
+    scan[threadIdx.x] = keep;
+    __syncthreads();
+    for (int off = 1; off < kPlocBlock; off <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (keep) tmp[(size_t)start + scan[threadIdx.x] - 1u] = value;
+    if (threadIdx.x == kPlocBlock - 1) block_count[blockIdx.x] = scan[threadIdx.x];
+}
+
+// exclusive scan of the block totals (one workgroup), total -> ctr[kCtrClusters]
+__global__ __launch_bounds__(1024) void k_ploc_scan(const uint32_t* __restrict__ block_count, uint32_t nb, uint32_t* __restrict__ block_offset,
+                                                    uint32_t* __restrict__ ctr)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; if (i < nb) sum += block_count[i]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; if (i < nb) { block_offset[i] = run; run += block_count[i]; } }
+    if (threadIdx.x == 1023) ctr[kCtrClusters] = part[1023];
+}
+
+__global__ __launch_bounds__(kPlocBlock) void k_ploc_gather(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ block_count,
+                                                            const uint32_t* __restrict__ block_offset, uint32_t* __restrict__ cout)
+{
+    if (threadIdx.x < block_count[blockIdx.x]) cout[block_offset[blockIdx.x] + threadIdx.x] = tmp[(size_t)blockIdx.x * kPlocBlock + threadIdx.x];
+}
+
+// the last m <= kPlocBlock clusters: all remaining rounds in one workgroup; the root's id ends up in ctr[kCtrClusters + 1]
+__global__ __launch_bounds__(kPlocBlock) void k_ploc_tail(const uint32_t* __restrict__ cin, uint32_t m, uint32_t nt,
+                                                          float4* __restrict__ bmin, float4* __restrict__ bmax, int2* __restrict__ child,
+                                                          uint32_t* __restrict__ ctr, int kRadius)
+{
+    __shared__ float4 smin[kPlocBlock], smax[kPlocBlock];
+    __shared__ uint32_t sid[kPlocBlock];
+    __shared__ int snn[kPlocBlock];
+    __shared__ uint32_t scan[kPlocBlock];
+    const int t = (int)threadIdx.x;
+    if (t < (int)m) { const uint32_t id = cin[t]; sid[t] = id; smin[t] = bmin[id]; smax[t] = bmax[id]; }
+    __syncthreads();
+    int cnt = (int)m;
+    while (cnt > 1) {
+        if (t < cnt) snn[t] = ploc_nearest(smin, smax, t, 0, cnt, kPlocBlock);     // the last clusters (the top of the tree) search all of them
+        __syncthreads();
+        uint32_t keep = 0, value = 0; float4 nmin = make_float4(0, 0, 0, 0), nmax = nmin;
+        if (t < cnt) {
+            const int j = snn[t];
+            const bool mutual = j >= 0 && snn[j] == t;
+            if (mutual && t < j) {
+                const uint32_t node = nt + atomicAdd(&ctr[kCtrNodes], 1u);
+                nmin = make_float4(__builtin_fminf(smin[t].x, smin[j].x), __builtin_fminf(smin[t].y, smin[j].y), __builtin_fminf(smin[t].z, smin[j].z), 0.f);
+                nmax = make_float4(__builtin_fmaxf(smax[t].x, smax[j].x), __builtin_fmaxf(smax[t].y, smax[j].y), __builtin_fmaxf(smax[t].z, smax[j].z), 0.f);
+                bmin[node] = nmin; bmax[node] = nmax;
+                child[node] = make_int2((int)sid[t], (int)sid[j]);
+                keep = 1; value = node;
+            } else if (!mutual) { keep = 1; value = sid[t]; nmin = smin[t]; nmax = smax[t]; }
+        }
+        scan[t] = keep;
+        __syncthreads();
+        for (int off = 1; off < kPlocBlock; off <<= 1) {
+            const uint32_t add = t >= off ? scan[t - off] : 0u;
+            __syncthreads();
+            scan[t] += add;
+            __syncthreads();
+        }
+        const int next = (int)scan[kPlocBlock - 1];
+        __syncthreads();
+        if (keep) { const int pos = (int)scan[t] - 1; sid[pos] = value; smin[pos] = nmin; smax[pos] = nmax; }
+        __syncthreads();
+        cnt = next;
+    }
+    if (t == 0) ctr[kCtrClusters + 1] = sid[0];
+}
+
+// ---- 4. collapse to 4-wide nodes, one level per launch --------------------------------------------------------------------
+__device__ __forceinline__ bool leaf_unit(uint32_t x, uint32_t nt, const int2* __restrict__ child)
+{
+    if (x < nt) return true;                                   // one triangle
+    const int2 c = child[x];
+    return (uint32_t)c.x < nt && (uint32_t)c.y < nt;           // two sibling triangles: one leaf
+}
+
+__global__ __launch_bounds__(256) void k_collapse_level(const uint2* __restrict__ fin, uint32_t nin, uint2* __restrict__ fout, uint32_t nt,
+                                                        const float4* __restrict__ bmin, const float4* __restrict__ bmax, const int2* __restrict__ child,
+                                                        const uint32_t* __restrict__ sorted_ids, rtbvh::Node4* __restrict__ nodes,
+                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ ctr, float G)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nin) return;
+    const uint32_t X = fin[i].x, slot = fin[i].y;
+    uint32_t kids[4]; int nk = 0;
+    if (leaf_unit(X, nt, child)) kids[nk++] = X;
+    else {
+        const int2 c = child[X];
+        kids[nk++] = (uint32_t)c.x; kids[nk++] = (uint32_t)c.y;
+        while (nk < 4) {                                       // open the internal child with the largest area
+            int pick = -1; float pa = -1.f;
+            for (int k = 0; k < nk; ++k)
+                if (!leaf_unit(kids[k], nt, child)) {
+                    const float ar = half_area(bmin[kids[k]], bmax[kids[k]]);
+                    if (ar > pa) { pa = ar; pick = k; }
+                }
+            if (pick < 0) break;
+            const int2 c2 = child[kids[pick]];
+            kids[pick] = (uint32_t)c2.x; kids[nk++] = (uint32_t)c2.y;
+        }
+    }
+    uint32_t n_int = 0, n_tri = 0;
+    for (int k = 0; k < nk; ++k) {
+        if (kids[k] < nt) n_tri += 1; else if (leaf_unit(kids[k], nt, child)) n_tri += 2; else n_int += 1;
+    }
+    const uint32_t nbase = n_int ? atomicAdd(&ctr[kCtrNode4], n_int) : 0u;
+    const uint32_t fbase = n_int ? atomicAdd(&ctr[kCtrFrontier], n_int) : 0u;
+    uint32_t obase = n_tri ? atomicAdd(&ctr[kCtrOrder], n_tri) : 0u;
+    rtbvh::Node4 N;
+    uint32_t ri = 0;
+    const float INF = __builtin_inff();
+    for (int k = 0; k < 4; ++k) {
+        if (k >= nk) {
+            N.minx[k] = N.miny[k] = N.minz[k] = INF; N.maxx[k] = N.maxy[k] = N.maxz[k] = -INF; N.child[k] = rtbvh::kEmpty;
+            continue;
+        }
+        const uint32_t x = kids[k];
+        const float4 mn = bmin[x], mx = bmax[x];
+        const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+        float plo[3], phi[3];
+        for (int a = 0; a < 3; ++a) {                          // bvh.cpp pad_box
+            const float m = __builtin_fmaxf(__builtin_fabsf(lo[a]), __builtin_fabsf(hi[a]));
+            const float e = 3e-5f * m + 2e-6f * G + 1e-30f;
+            plo[a] = lo[a] - e; phi[a] = hi[a] + e;
+        }
+        N.minx[k] = plo[0]; N.miny[k] = plo[1]; N.minz[k] = plo[2];
+        N.maxx[k] = phi[0]; N.maxy[k] = phi[1]; N.maxz[k] = phi[2];
+        if (x < nt) { order[obase] = sorted_ids[x]; N.child[k] = rtbvh::kLeafBit | (obase << 2) | 0u; obase += 1; }
+        else if (leaf_unit(x, nt, child)) {
+            const int2 c = child[x];
+            order[obase] = sorted_ids[c.x]; order[obase + 1] = sorted_ids[c.y];
+            N.child[k] = rtbvh::kLeafBit | (obase << 2) | 1u; obase += 2;
+        } else {
+            N.child[k] = nbase + ri;
+            fout[fbase + ri] = make_uint2(x, nbase + ri);
+            ++ri;
+        }
+    }
+    N.meta[0] = (uint32_t)nk; N.meta[1] = N.meta[2] = N.meta[3] = 0u;
+    nodes[slot] = N;
+}
+
+// ---- 5. worst-case traversal stack, bottom-up over the levels -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stack_need(const rtbvh::Node4* __restrict__ nodes, uint32_t n0, uint32_t n1, int* __restrict__ need)
+{
+    const uint32_t i = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const int k = (int)nodes[i].meta[0];
+    int deepest = 0;
+    for (int s = 0; s < k; ++s) { const uint32_t c = nodes[i].child[s]; if (!(c & rtbvh::kLeafBit)) deepest = max(deepest, need[c]); }
+    need[i] = (k - 1) + deepest;
+}
+
+// sum of the areas of all internal child boxes (the part of the SAH the topology decides): refit quality monitor
+__global__ __launch_bounds__(256) void k_internal_area(const rtbvh::Node4* __restrict__ nodes, uint32_t nn, float* __restrict__ out)
+{
+    float s = 0.f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        const rtbvh::Node4& N = nodes[i];
+        for (int k = 0; k < 4; ++k)
+            if (N.child[k] != rtbvh::kEmpty) {
+                const float dx = N.maxx[k] - N.minx[k], dy = N.maxy[k] - N.miny[k], dz = N.maxz[k] - N.minz[k];
+                const float a = dx * dy + dy * dz + dz * dx;
+                if (a == a && a < 3.0e38f) s += a;
+            }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// ---- host driver ------------------------------------------------------------------------------------------------------------------
+template <class T> struct Buf {
+    T* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = std::max<size_t>(n, 1);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace {
+    Buf<uint64_t> keys0, keys1;
+    Buf<uint32_t> ids0, ids1, c0, c1, tmp, block_count, block_offset, ctr;
+    Buf<unsigned char> sort_tmp;
+    Buf<float4> bmin, bmax;
+    Buf<int2> child;
+    Buf<uint2> f0, f1;
+    Buf<int> need;
+    Buf<float> area;
+    void release()
+    {
+        keys0.release(); keys1.release(); ids0.release(); ids1.release(); c0.release(); c1.release(); tmp.release(); block_count.release();
+        block_offset.release(); ctr.release(); sort_tmp.release(); bmin.release(); bmax.release(); child.release(); f0.release(); f1.release();
+        need.release(); area.release();
+    }
+};
+
+struct Result {
+    uint32_t n_nodes = 0;
+    int max_stack = 0, rounds = 0, levels = 0;
+    float magnitude = 0.f;                  // G used for the padding
+    std::vector<uint32_t> level_start;      // nodes of level L are [level_start[L], level_start[L+1])
+};
+
+#define RTGB_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+// tris: nt world-space triangles (18 floats each) on the device.  nodes: room for nt + 1 Node4 records; order: nt entries.
+// origin_magnitude: largest |coordinate| of a ray origin outside the triangles (camera, spheres).
+inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, float origin_magnitude, int radius, Workspace& w,
+                        rtbvh::Node4* nodes, uint32_t* order, Result& out)
+{
+    radius = std::max(1, std::min(radius, kMaxRadius));
+    out = Result();
+    if (nt == 0) return hipSuccess;
+    const uint32_t nb0 = (nt + kPlocBlock - 1) / kPlocBlock;
+    RTGB_HIP(w.keys0.ensure(nt)); RTGB_HIP(w.keys1.ensure(nt)); RTGB_HIP(w.ids0.ensure(nt)); RTGB_HIP(w.ids1.ensure(nt));
+    RTGB_HIP(w.c0.ensure(nt)); RTGB_HIP(w.c1.ensure(nt)); RTGB_HIP(w.tmp.ensure((size_t)nb0 * kPlocBlock));
+    RTGB_HIP(w.block_count.ensure(nb0)); RTGB_HIP(w.block_offset.ensure(nb0)); RTGB_HIP(w.ctr.ensure(32));
+    RTGB_HIP(w.bmin.ensure(2 * (size_t)nt)); RTGB_HIP(w.bmax.ensure(2 * (size_t)nt)); RTGB_HIP(w.child.ensure(2 * (size_t)nt));
+    RTGB_HIP(w.f0.ensure(nt)); RTGB_HIP(w.f1.ensure(nt)); RTGB_HIP(w.need.ensure((size_t)nt + 1)); RTGB_HIP(w.area.ensure(1));
+
+    uint32_t h_ctr[32] = {};
+    for (int a = 0; a < 3; ++a) { h_ctr[kCtrBounds + a] = 0xFFFFFFFFu; h_ctr[kCtrBounds + 3 + a] = 0u; }
+    h_ctr[kCtrNode4] = 1u;                                     // node 0 = the root
+    RTGB_HIP(hipMemcpyAsync(w.ctr.p, h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, stream));
+    const int grid = (int)std::min<uint32_t>((nt + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_tri_bounds, dim3(grid), dim3(256), 0, stream, tris, nt, w.ctr.p);
+    hipLaunchKernelGGL(k_morton, dim3((nt + 255) / 256), dim3(256), 0, stream, tris, nt, w.ctr.p, w.keys0.p, w.ids0.p);
+    size_t tmp_bytes = 0;
+    RTGB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, w.keys0.p, w.keys1.p, w.ids0.p, w.ids1.p, (int)nt, 0, 63, stream));
+    RTGB_HIP(w.sort_tmp.ensure(tmp_bytes));
+    RTGB_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp.p, tmp_bytes, w.keys0.p, w.keys1.p, w.ids0.p, w.ids1.p, (int)nt, 0, 63, stream));
+    hipLaunchKernelGGL(k_leaf_boxes, dim3((nt + 255) / 256), dim3(256), 0, stream, tris, w.ids1.p, nt, w.bmin.p, w.bmax.p, w.c0.p);
+
+    // ---- PLOC rounds
+    uint32_t m = nt;
+    uint32_t* cin = w.c0.p; uint32_t* cout = w.c1.p;
+    while (m > (uint32_t)kPlocBlock) {
+        const uint32_t nb = (m + kPlocBlock - 1) / kPlocBlock;
+        hipLaunchKernelGGL(k_ploc_round, dim3(nb), dim3(kPlocBlock), 0, stream, cin, m, nt, w.bmin.p, w.bmax.p, w.child.p, w.ctr.p, w.tmp.p, w.block_count.p, radius);
+        hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, stream, w.block_count.p, nb, w.block_offset.p, w.ctr.p);
+        hipLaunchKernelGGL(k_ploc_gather, dim3(nb), dim3(kPlocBlock), 0, stream, w.tmp.p, w.block_count.p, w.block_offset.p, cout);
+        uint32_t m_next = 0;
+        RTGB_HIP(hipMemcpyAsync(&m_next, w.ctr.p + kCtrClusters, sizeof m_next, hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipStreamSynchronize(stream));
+        if (m_next == 0 || m_next >= m) return hipErrorUnknown;           // (cannot happen: every round merges at least one pair)
+        m = m_next; std::swap(cin, cout); ++out.rounds;
+    }
+    hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocBlock), 0, stream, cin, m, nt, w.bmin.p, w.bmax.p, w.child.p, w.ctr.p, radius);
+    uint32_t root = 0; uint32_t h_bounds[8];
+    RTGB_HIP(hipMemcpyAsync(&root, w.ctr.p + kCtrClusters + 1, sizeof root, hipMemcpyDeviceToHost, stream));
+    RTGB_HIP(hipMemcpyAsync(h_bounds, w.ctr.p + kCtrBounds, sizeof h_bounds, hipMemcpyDeviceToHost, stream));
+    RTGB_HIP(hipStreamSynchronize(stream));
+    const float G = std::max(origin_magnitude, ord2f(h_bounds[6]));
+    out.magnitude = G;
+
+    // ---- collapse, level by level
+    const uint2 first = make_uint2(root, 0u);
+    RTGB_HIP(hipMemcpyAsync(w.f0.p, &first, sizeof first, hipMemcpyHostToDevice, stream));
+    uint2* fin = w.f0.p; uint2* fout = w.f1.p;
+    uint32_t nin = 1, total = 1;
+    out.level_start.push_back(0);
+    while (nin > 0) {
+        RTGB_HIP(hipMemsetAsync(w.ctr.p + kCtrFrontier, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_collapse_level, dim3((nin + 255) / 256), dim3(256), 0, stream, fin, nin, fout, nt, w.bmin.p, w.bmax.p, w.child.p,
+                           w.ids1.p, nodes, order, w.ctr.p, G);
+        uint32_t nout = 0;
+        RTGB_HIP(hipMemcpyAsync(&nout, w.ctr.p + kCtrFrontier, sizeof nout, hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipStreamSynchronize(stream));
+        out.level_start.push_back(total);
+        total += nout; nin = nout; std::swap(fin, fout); ++out.levels;
+    }
+    out.n_nodes = total;
+    if (out.level_start.back() != total) out.level_start.push_back(total);
+    // ---- exact worst-case stack depth
+    for (int L = (int)out.level_start.size() - 2; L >= 0; --L) {
+        const uint32_t n0 = out.level_start[L], n1 = out.level_start[L + 1];
+        if (n1 > n0) hipLaunchKernelGGL(k_stack_need, dim3((n1 - n0 + 255) / 256), dim3(256), 0, stream, nodes, n0, n1, w.need.p);
+    }
+    int need0 = 0;
+    RTGB_HIP(hipMemcpyAsync(&need0, w.need.p, sizeof need0, hipMemcpyDeviceToHost, stream));
+    RTGB_HIP(hipStreamSynchronize(stream));
+    out.max_stack = std::max(1, need0);
+    return hipGetLastError();
+}
+
+// sum of internal child-box areas of the current nodes (synchronous, one float back)
+inline hipError_t internal_area(hipStream_t stream, const rtbvh::Node4* nodes, uint32_t nn, Workspace& w, float& area)
+{
+    area = 0.f;
+    if (!nn) return hipSuccess;
+    RTGB_HIP(w.area.ensure(1));
+    RTGB_HIP(hipMemsetAsync(w.area.p, 0, sizeof(float), stream));
+    hipLaunchKernelGGL(k_internal_area, dim3((int)std::min<uint32_t>((nn + 255) / 256, 1024)), dim3(256), 0, stream, nodes, nn, w.area.p);
+    RTGB_HIP(hipMemcpyAsync(&area, w.area.p, sizeof(float), hipMemcpyDeviceToHost, stream));
+    return hipStreamSynchronize(stream);
+}
+
+#undef RTGB_HIP
+
+} // namespace rtgb

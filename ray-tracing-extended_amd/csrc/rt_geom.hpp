@@ -93,9 +93,15 @@ __global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ worl
     const float ex = t[3] - t[0], ey = t[4] - t[1], ez = t[5] - t[2];          // RayTriangle :152-154
     const float fx = t[6] - t[0], fy = t[7] - t[1], fz = t[8] - t[2];
     const float nx = ey * fz - ez * fy, ny = ez * fx - ex * fz, nz = ex * fy - ey * fx;
+    if (tri_chunk[orig] == 0xFFFFFFFFu) {
+        // a triangle no chunk addresses is never visited by the reference's loops (RayTracing.shader:276-294): NaN records can never be hit
+        const float q = __uint_as_float(0x7FC00000u);
+        tri_geo[3 * (size_t)i + 0] = tri_geo[3 * (size_t)i + 1] = tri_geo[3 * (size_t)i + 2] = make_float4(q, q, q, q);
+    } else {
     tri_geo[3 * (size_t)i + 0] = make_float4(t[0], t[1], t[2], ex);
     tri_geo[3 * (size_t)i + 1] = make_float4(ey, ez, fx, fy);
     tri_geo[3 * (size_t)i + 2] = make_float4(fz, nx, ny, nz);
+    }
     tri_nrm[3 * (size_t)i + 0] = make_float4(t[9], t[10], t[11], __uint_as_float(tri_chunk[orig]));
     tri_nrm[3 * (size_t)i + 1] = make_float4(t[12], t[13], t[14], __uint_as_float(tri_rank[orig]));   // tie-break key: visiting rank
     tri_nrm[3 * (size_t)i + 2] = make_float4(t[15], t[16], t[17], 0.f);

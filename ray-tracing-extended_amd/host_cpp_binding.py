@@ -31,14 +31,6 @@ def load_host_library():
         _lib = L
     return _lib
 
-    def render_multi(self, frames: int, devices) -> np.ndarray:
-        """RayTracingManager::OnRenderImage(rt_multi*, frames): the frame tiled over len(devices) contexts; returns [H, W, 4]."""
-        out = np.empty((self.height, self.width, 4), np.float32)
-        arr = (c_int * len(devices))(*devices)
-        if self._L.rth_render_multi(self._h, arr, len(devices), frames, out.ctypes.data_as(POINTER(c_float))):
-            raise RtError("OnRenderImage(rt_multi): " + self._L.rth_last_error().decode())
-        return out
-
 
 def cpp_split_mesh(vertices, normals, indices, sub_ranges, mode=0, transform=None, seed=None, enforce_limit=True):
     """The compiled host's MeshSplitter::CreateChunks (mode 0), RayTracedMesh::GetSubMeshes on a mesh without cached chunks
@@ -101,4 +93,12 @@ class CppScene:
         out = np.empty((self.height, self.width, 4), np.float32)
         if self._L.rth_render(self._h, device, frames, out.ctypes.data_as(POINTER(c_float))):
             raise RtError("OnRenderImage: " + self._L.rth_last_error().decode())
+        return out
+
+    def render_multi(self, frames: int, devices) -> np.ndarray:
+        """RayTracingManager::OnRenderImage(rt_multi*, frames): the frame tiled over len(devices) contexts; returns [H, W, 4]."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        arr = (c_int * len(devices))(*devices)
+        if self._L.rth_render_multi(self._h, arr, len(devices), frames, out.ctypes.data_as(POINTER(c_float))):
+            raise RtError("OnRenderImage(rt_multi): " + self._L.rth_last_error().decode())
         return out

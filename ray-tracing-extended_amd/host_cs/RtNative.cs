@@ -120,6 +120,13 @@ namespace RtMi355x
         public int autoKernel;
         public int lastKernel;
         public int lastFramesInterleaved;
+        public double lastBvhBuildMs;
+        public float refitAreaRatio;
+        public float bvhInternalArea;
+        public int bvhBuiltOnDevice;
+        public int bvhBuilds;
+        public int bvhRebuilds;
+        public int _reserved;
     }
 
     public enum RngMode { Pcg = 0, Philox = 1 }

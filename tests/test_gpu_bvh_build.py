@@ -1,0 +1,129 @@
+"""The BVH builders: the device builder (Morton order + PLOC + breadth-first collapse, csrc/rt_bvh_gpu.hpp) against the host's
+binned-SAH builder and the oracle.  A hierarchy only prunes, so every tree must give the same image; what differs is the build
+time and the traversal work per ray, and both are checked against the bars of the round (1M triangles in < 5 ms; work per ray
+within 15 % of the host tree)."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bitwise, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_with(tracer, b, builder, frames=2, counting=False, want_bvh=False, **opts):
+    params, spheres, tris, infos = b
+    tracer.set_option("device_bvh", builder)
+    for k, v in opts.items():
+        tracer.set_option(k, v)
+    try:
+        tracer.set_option("kernel", 1)
+        tracer.set_rows(0, int(params["height"]))
+        tracer.set_params(params)
+        tracer.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+        tracer.reset_accum()
+        (tracer.render_counting if counting else tracer.render)(0, frames)
+        if want_bvh:
+            return tracer.read_accum(), tracer.stats(), tracer.read_bvh()
+        return tracer.read_accum(), tracer.stats()
+    finally:
+        tracer.set_option("device_bvh", -1)
+        tracer.set_option("bvh_radius", 16)
+
+
+@pytest.mark.parametrize("radius", [1, 16, 64])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_device_built_tree_gives_the_oracles_image(rtx, oracle, tracer, mode, radius):
+    b = list(rtx.scenes.mesh_test_scene(96, 64).build_buffers())
+    b[0] = b[0].copy(); b[0]["intersectMode"] = mode
+    got, st = _render_with(tracer, b, 1, bvh_radius=radius)
+    assert st["bvhBuiltOnDevice"] == 1 and st["numBvhNodes"] > 10
+    want, _, cnt = oracle.render(*b, 0, 2, mode=mode)
+    assert_bitwise(got, want, f"device tree (radius {radius}), mode {mode}")
+    assert st["rays"] == cnt["rays"]
+    host, sth = _render_with(tracer, b, 0)
+    assert sth["bvhBuiltOnDevice"] == 0
+    assert_bitwise(host, want, "host tree")
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 47, 513, 1025])
+def test_device_builder_small_and_awkward_triangle_counts(rtx, oracle, tracer, n):
+    """1 triangle (a root with one leaf), 2 (one leaf pair), counts around the single-workgroup threshold of the clustering
+    (512 clusters), exact duplicates and a NaN triangle among them: image == oracle, every triangle reachable."""
+    rng = np.random.default_rng(n)
+    m = rtx.scenes.mesh_test_scene(48, 32)
+    params, spheres, _, _ = m.build_buffers()
+    tris = np.zeros(n, rtx.TRIANGLE)
+    c = rng.uniform([-3, 0, -2], [3, 3, 4], (n, 1, 3)).astype(np.float32)
+    p = c + rng.uniform(-0.6, 0.6, (n, 3, 3)).astype(np.float32)
+    if n >= 5:
+        p[3] = p[2]                               # an exact duplicate
+        p[4, 1, 0] = np.nan
+    tris["posA"], tris["posB"], tris["posC"] = p[:, 0], p[:, 1], p[:, 2]
+    nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]).astype(np.float32)
+    for f in ("normalA", "normalB", "normalC"):
+        tris[f] = nrm
+    infos = np.zeros(1, rtx.MESHINFO)
+    infos["numTriangles"] = n
+    infos["material"]["colour"] = (0.8, 0.7, 0.6, 1); infos["material"]["emissionColour"] = (1, 1, 1, 1); infos["material"]["emissionStrength"] = 0.5
+    with np.errstate(invalid="ignore"):
+        infos["boundsMin"], infos["boundsMax"] = np.nanmin(p.reshape(-1, 3), 0) - 1, np.nanmax(p.reshape(-1, 3), 0) + 1
+    b = (params, spheres, tris, infos)
+    got, st, (f32, _) = _render_with(tracer, b, 1, want_bvh=True)
+    want, _, cnt = oracle.render(*b, 0, 2)
+    assert_bitwise(got, want, f"{n} triangles through the device builder")
+    assert st["rays"] == cnt["rays"] and st["bvhBuiltOnDevice"] == 1
+    refs = f32[:, 24:28].ravel()
+    leaves = refs[(refs & 0x80000000) != 0]
+    leaves = leaves[leaves != 0xFFFFFFFF]
+    assert int(((leaves & 3) + 1).sum()) == n      # every triangle sits in exactly one leaf
+
+
+def test_device_builder_meets_the_build_time_and_quality_bars(rtx, tracer):
+    """100,440 and 1,004,364 triangles: build time (HIP events around sort + clustering + collapse + triangle records + f16 nodes)
+    under 5 ms, traversal work per ray (node visits + triangle tests, counting build, 480x270 x 2 rays) within 15 % of the host's
+    binned-SAH tree, same image."""
+    for gen, tri_count in ((rtx.scenes.config3, 100440), (rtx.scenes.config5, 1004364)):
+        m = gen(480, 270)
+        m.numRaysPerPixel = 2
+        b = m.build_buffers()
+        assert len(b[2]) == tri_count
+        host_img, sh = _render_with(tracer, b, 0, frames=1, counting=True)
+        _render_with(tracer, b, 1, frames=1, counting=True)             # first device build pays the workspace allocations
+        dev_img, sd = _render_with(tracer, b, 1, frames=1, counting=True)
+        assert_bitwise(dev_img, host_img, f"{tri_count} triangles: device tree vs host tree")
+        work_h = (sh["nodeVisits"] + sh["triTests"]) / sh["rays"]
+        work_d = (sd["nodeVisits"] + sd["triTests"]) / sd["rays"]
+        assert sd["bvhBuiltOnDevice"] == 1 and sd["lastBvhBuildMs"] < 5.0, sd["lastBvhBuildMs"]
+        assert work_d <= 1.15 * work_h, (tri_count, work_d, work_h)
+        assert sd["bvhMaxStack"] < 64
+
+
+def test_refit_that_inflates_the_tree_triggers_a_device_rebuild(rtx, tracer):
+    """On-device geometry pipeline: small moves refit (topology kept); spreading the meshes far apart inflates the refitted boxes
+    past rebuild_percent and the tree is rebuilt on the device — the image equals a fresh host-transformed upload either way."""
+    from test_gpu_geometry import upload_local
+    mgr = rtx.scenes.mesh_test_scene(96, 64)
+    upload_local(tracer, mgr)
+    tracer.reset_accum()
+    tracer.render(0, 1)
+    st0 = tracer.stats()
+    assert st0["bvhBuiltOnDevice"] == 1 and st0["bvhRebuilds"] == 0
+    h = rtx.host
+    for step, spread in enumerate((1.02, 6.0)):
+        for i, mesh in enumerate(mgr.meshes[2:]):
+            mesh.transform = h.Transform(position=mesh.transform.position * np.float32([spread, 1.0, spread]) + np.float32([0, 0.05 * i, 0]),
+                                         rotation=mesh.transform.rotation, lossyScale=mesh.transform.lossyScale)
+        tracer.set_mesh_transforms(mgr.build_transforms())
+        tracer.reset_accum()
+        tracer.render(2, 2)
+        got = tracer.read_accum()
+        st = tracer.stats()
+        if step == 0:
+            assert st["bvhRebuilds"] == st0["bvhRebuilds"] and st["refitAreaRatio"] < 2.0
+        else:
+            assert st["bvhRebuilds"] == st0["bvhRebuilds"] + 1, st["refitAreaRatio"]
+        want, _ = run_gpu(tracer, mgr.build_buffers(), 2, 2, kernel=-1)
+        assert_bitwise(got, want, f"spread {spread}: device pipeline vs fresh upload")
+        upload_local(tracer, mgr)
+        tracer.render(0, 1)
+        st0 = tracer.stats()

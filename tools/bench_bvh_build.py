@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""BVH builders side by side on the 100k- and 1M-triangle workloads: build time, tree size, worst-case stack, traversal work per
+ray (counting build of the tracer, 960x540 x 4 rays, frame 0), and that both trees give the same image.  JSON on stdout."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import rtx_pkg
+
+rtx = rtx_pkg.load()
+
+
+def main():
+    out = []
+    configs = [a for a in sys.argv[1:] if "=" not in a] or ["config3", "config5"]
+    opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+    for name in configs:
+        mgr = getattr(rtx.scenes, name)(960, 540)
+        mgr.numRaysPerPixel = 4
+        params, spheres, tris, infos = mgr.build_buffers()
+        if "drop_big" in opts:                                # diagnostic: the scene without its few huge triangles (floor, light)
+            ext = np.maximum(np.maximum(tris["posA"], tris["posB"]), tris["posC"]) - np.minimum(np.minimum(tris["posA"], tris["posB"]), tris["posC"])
+            big = ext.max(axis=1) > 20.0
+            keep = np.cumsum(~big) - 1
+            infos = infos.copy()
+            new_first, new_count = [], []
+            for mi in infos:
+                a, n = int(mi["firstTriangleIndex"]), int(mi["numTriangles"])
+                sel = ~big[a:a + n]
+                new_first.append(int(keep[a:a + n][sel][0]) if sel.any() else 0); new_count.append(int(sel.sum()))
+            infos["firstTriangleIndex"], infos["numTriangles"] = new_first, new_count
+            tris = tris[~big]
+        images = {}
+        for builder in ("host", "device"):
+            tr = rtx.Tracer(0)
+            tr.set_option("device_bvh", 1 if builder == "device" else 0)
+            tr.set_option("kernel", 1)
+            for k, v in opts.items():
+                if k != "drop_big":
+                    tr.set_option(k, int(v))
+            tr.set_params(params)
+            tr.set_rows(0, 540)
+            times = []
+            for rep in range(3):                              # rebuilds of the same scene: the first one pays allocations
+                tr.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+                t0 = time.perf_counter()
+                tr.render(0, 0)                               # n_frames = 0: scene build only
+                wall = (time.perf_counter() - t0) * 1e3
+                times.append((tr.stats()["lastBvhBuildMs"], wall))
+            tr.reset_accum()
+            tr.render_counting(0, 1)
+            st = tr.stats()
+            images[builder] = tr.read_last_frame()
+            rec = {"workload": name, "builder": builder, "options": opts, "triangles": int(len(tris)), "bvh_nodes": st["numBvhNodes"], "max_stack": st["bvhMaxStack"], "internal_area": st["bvhInternalArea"],
+                   "build_ms": [round(t[0], 3) for t in times], "upload_plus_build_wall_ms": [round(t[1], 2) for t in times],
+                   "nodes_per_ray": round(st["nodeVisits"] / st["rays"], 3), "tris_per_ray": round(st["triTests"] / st["rays"], 3),
+                   "rays": st["rays"]}
+            rec["nodes_plus_tris_per_ray"] = round(rec["nodes_per_ray"] + rec["tris_per_ray"], 3)
+            out.append(rec)
+            tr.close()
+        same = np.array_equal(images["host"].view(np.uint32), images["device"].view(np.uint32))
+        out[-1]["same_image_as_host_tree"] = bool(same)
+        out[-1]["work_ratio_vs_host"] = round(out[-1]["nodes_plus_tris_per_ray"] / out[-2]["nodes_plus_tris_per_ray"], 4)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
