@@ -751,6 +751,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     if (c->auto_choice >= 0 && !c->scene_dirty && order_ready())
         return launch_frames_k(c, first_frame, n_frames, var, decided(n_frames));
 
+    if (n_frames == 0) return launch_frames_k(c, first_frame, 0, var, c->auto_choice >= 0 ? c->auto_choice : 0);   // scene / geometry update only
     rt_stats sum{}; bool any = false;
     auto add = [&]() {
         const rt_stats& s = c->stats;

@@ -309,11 +309,11 @@ void RayTracingManager::InitFrame(rt_ctx* ctx)
 {
     SceneBuffers b = BuildBuffers();
     check(ctx, rt_set_params(ctx, &b.params), "rt_set_params");
-    if (!uploaded_) {       // the reference re-uploads every frame (its TODO at RayTracedMesh.cs:37); once is enough here
+    if (uploaded_to_ != ctx) {       // the reference re-uploads every frame (its TODO at RayTracedMesh.cs:37); once per context is enough here
         check(ctx, rt_upload_spheres(ctx, b.spheres.data(), (int)b.spheres.size()), "rt_upload_spheres");
         check(ctx, rt_upload_triangles(ctx, b.triangles.data(), (int)b.triangles.size()), "rt_upload_triangles");
         check(ctx, rt_upload_meshinfo(ctx, b.meshInfo.data(), (int)b.meshInfo.size()), "rt_upload_meshinfo");
-        uploaded_ = true;
+        uploaded_to_ = ctx;
     }
 }
 
@@ -343,11 +343,11 @@ void RayTracingManager::InitFrame(rt_multi* m)
 {
     SceneBuffers b = BuildBuffers();
     mcheck(m, rt_multi_set_params(m, &b.params), "rt_multi_set_params");
-    if (!uploaded_) {
+    if (uploaded_to_ != m) {
         mcheck(m, rt_multi_upload_spheres(m, b.spheres.data(), (int)b.spheres.size()), "rt_multi_upload_spheres");
         mcheck(m, rt_multi_upload_triangles(m, b.triangles.data(), (int)b.triangles.size()), "rt_multi_upload_triangles");
         mcheck(m, rt_multi_upload_meshinfo(m, b.meshInfo.data(), (int)b.meshInfo.size()), "rt_multi_upload_meshinfo");
-        uploaded_ = true;
+        uploaded_to_ = m;
     }
 }
 

@@ -130,8 +130,11 @@ public:
     void InitFrame(rt_multi* multi);
     void OnRenderImage(rt_multi* multi, int frames, std::vector<float>* resultTexture = nullptr);
     void Start(rt_multi* multi);
+    // :190-194 — the reference releases its buffers here; the library owns them, so this only forgets which context holds them
+    // (call it before destroying the context: the next InitFrame uploads again)
+    void OnDisable() { uploaded_to_ = nullptr; }
 private:
-    bool uploaded_ = false;
+    const void* uploaded_to_ = nullptr;         // the context (or rt_multi) that holds this manager's buffers
 };
 
 // Loads a reference scene (Unity YAML).  Throws std::runtime_error with a message on malformed input.

@@ -61,6 +61,7 @@ int rth_render(void* hp, int device, int frames, float* rgba)
         h->mgr.OnRenderImage(ctx, frames, &out);
         std::memcpy(rgba, out.data(), out.size() * sizeof(float));
     } catch (const std::exception& e) { g_err = e.what(); rc = -1; }
+    h->mgr.OnDisable();
     rt_destroy(ctx);
     return rc;
 }
@@ -74,7 +75,8 @@ int rth_render_multi(void* hp, const int* devices, int n_contexts, int frames, f
     int rc = 0;
     try {
         std::vector<float> out;
-        rthost::RayTracingManager mgr = h->mgr;          // a fresh manager state (nothing uploaded yet) for this handle
+        rthost::RayTracingManager mgr = h->mgr;
+        mgr.OnDisable();                                 // (a copy of the handle's manager: nothing uploaded to this rt_multi yet)
         mgr.Start(m);
         mgr.OnRenderImage(m, frames, &out);
         std::memcpy(rgba, out.data(), out.size() * sizeof(float));
