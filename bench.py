@@ -39,7 +39,7 @@ VMEM_CYCLES_PER_WAVE_LOAD = 16.2     # tools/ubench/vmem_rate.hip (profiles/uben
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, help="workload: 2 (12 spheres), 3 (~100k tris, headline), 4 (same scene at 3840x2160, 12 bounces), 5 (~1M tris, DOF)")
     ap.add_argument("--width", type=int, default=0)
@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
     ap.add_argument("--no-latency", action="store_true", help="skip the (untimed) single-frame latency measurements")
+    ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
+                    help="diagnostic on one GPU: render only what rank 0 of N ranks would (bands 0, N, 2N, ...): the compute side of the N-GPU "
+                         "strong-scaling run without the gather; the printed value is this rank's own rate, not a job rate")
     return ap.parse_args()
 
 
@@ -149,7 +152,11 @@ def main():
         buffers = (params, spheres, tris, infos)
     W, H = int(params["width"]), int(params["height"])
     banded = world > 1 and args.decomposition == "bands"
-    if banded:      # 8-row bands dealt round-robin: sky rows and object rows spread evenly over the ranks
+    sim = args.as_rank_of if world == 1 and args.as_rank_of > 1 else 0
+    if sim:
+        my_rows = rtx.distributed.band_rows(H, sim, 0)
+        row0, nrows, rows = 0, len(my_rows), rtx.distributed.band_rows_padded(H, sim)
+    elif banded:      # 8-row bands dealt round-robin: sky rows and object rows spread evenly over the ranks
         my_rows = rtx.distributed.band_rows(H, world, rank)
         row0, nrows, rows = rank * 8, len(my_rows), rtx.distributed.band_rows_padded(H, world)
     else:
@@ -158,7 +165,9 @@ def main():
     tr = rtx.Tracer(dev_index)
     tr.set_params(params)
     tr.upload(spheres=spheres, triangles=tris, meshinfo=infos)
-    if banded:
+    if sim:
+        tr.set_bands(0, sim)
+    elif banded:
         tr.set_bands(rank, world)
     else:
         tr.set_rows(row0, nrows)
@@ -292,7 +301,7 @@ def main():
 
     # ---- latency of one rt_render_frame, camera fixed and camera moved before every frame (untimed extras, rank 0, N = 1)
     latency = None
-    if world == 1 and not args.no_latency:
+    if world == 1 and not args.no_latency and not sim:
         tr.reset_accum()
         tr.render_frame(0)
         t0 = time.perf_counter()
@@ -335,7 +344,8 @@ def main():
         "config": {"workload": f"{names[args.config]}, {W}x{H}, {int(params['numRaysPerPixel'])} rays/pixel/frame "
                                f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, {args.rng.upper()}, FLAT_CHUNKS semantics",
                    "decomposition": (f"{world} ranks, " + ("interleaved 8-row bands" if banded else "contiguous row strips")
-                                     + " + one RCCL gather") if world > 1 else "single GPU",
+                                     + " + one RCCL gather") if world > 1 else
+                                    (f"diagnostic: rank 0 of {sim} (its interleaved bands only, no gather)" if sim else "single GPU"),
                    "rays_per_frame": int(total_rays / max(args.steps, 1)),
                    "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres)),
                    "per_gpu_kernel_ms": busy},

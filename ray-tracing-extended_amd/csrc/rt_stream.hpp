@@ -30,10 +30,11 @@ struct StreamArgs {
     int tiles_per_fetch;        // tile_sync: a wave reserves this many consecutive work items at a time; a lane that finishes its
                                 // pixel of one moves on to its position in the next without waiting for the slower lanes
     int tile_sync;              // 1: a wave takes a whole 8x8 tile at a time (coherent lanes), 0: lanes refill pixel by pixel
-    int fg_log2;                // tile_sync: a work item is a sub-tile of 64 >> fg_log2 pixels (8x8, 4x4 or 2x2) in 1 << fg_log2 consecutive
-                                // frames of the launch (0, 2, 4): lane = (frame sub-index, pixel of the sub-tile).  Frames are
-                                // independent (frag :362 seeds by Frame), so the same pixel in 4 or 16 frames gives a wave rays that
-                                // start almost identical and per-lane costs that are identically distributed
+    int n16, n4, n1;            // tile_sync: the launch's frames as n16 groups of 16, then n4 groups of 4, then n1 single frames.  A work
+                                // item is a sub-tile of 2x2 / 4x4 / 8x8 pixels in the 16 / 4 / 1 frames of a group: lane = (frame of the
+                                // group, pixel of the sub-tile).  Frames are independent (frag :362 seeds by Frame), so the same pixel
+                                // in 16 or 4 frames gives a wave rays that start almost identical and per-lane costs that are
+                                // identically distributed
 };
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
@@ -93,20 +94,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     unsigned int group_base = 0, group_len = 0, kidx = 0;   // items [group_base, group_base + group_len) belong to this wave; kidx: this lane's
 
     // Give this lane its position's pixel of work item `item` = (frame, tile); false when the tile has no pixel there.
-    // Work items: frame group g (1 << fg_log2 frames) x 8x8 tile (costliest first) x sub-tile of the tile.
-    const int fgl = A.fg_log2, pxl = 6 - fgl, swl = pxl >> 1;       // log2 of: frames per item, pixels per sub-tile, sub-tile width
+    // Work items: frame group (16, 4 or 1 frames) x 8x8 tile (costliest first) x sub-tile of the tile.  The frames of a launch are
+    // cut into A.n16 groups of 16, then A.n4 groups of 4, then A.n1 single frames; all their items sit in one queue, so whatever the
+    // frame count the launch has one tail.
     const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-    const unsigned int per_group_ = ntiles_ << fgl;
-    const unsigned int nframes_ = (unsigned)(F.frames_in_launch > 1 ? F.frames_in_launch : 1);
-    const unsigned int nitems_ = per_group_ * ((nframes_ + (1u << fgl) - 1u) >> fgl);
+    const unsigned int items16_ = (unsigned)A.n16 * (ntiles_ << 4), items4_ = (unsigned)A.n4 * (ntiles_ << 2);
+    const unsigned int nitems_ = items16_ + items4_ + (unsigned)A.n1 * ntiles_;
+    const unsigned int nframes_ = (unsigned)(A.n16 * 16 + A.n4 * 4 + A.n1);
+    // item -> its 8x8 tile (before the costliest-first permutation), sub-tile, first frame and log2 of its frame count
+    auto decode = [&](unsigned int item, unsigned int& tile, unsigned int& sub, unsigned int& frame0) -> int {
+        int fgl = 4; unsigned int fbase = 0;
+        if (item >= items16_) { item -= items16_; fgl = 2; fbase = (unsigned)A.n16 * 16u; if (item >= items4_) { item -= items4_; fgl = 0; fbase += (unsigned)A.n4 * 4u; } }
+        const unsigned int per_group = ntiles_ << fgl;
+        const unsigned int g = item / per_group, r = item - g * per_group;
+        tile = r >> fgl; sub = r & ((1u << fgl) - 1u); frame0 = fbase + (g << fgl);
+        return fgl;
+    };
     auto start_pixel = [&](unsigned int item) -> bool {
-        const unsigned int g = item / per_group_;
-        const unsigned int r = item - g * per_group_;
-        unsigned int tile = r >> fgl;
-        const unsigned int sub = r & ((1u << fgl) - 1u);
+        unsigned int tile, sub, frame0;
+        const int fgl = decode(item, tile, sub, frame0);
+        const int pxl = 6 - fgl, swl = pxl >> 1;              // log2 of: pixels per sub-tile, sub-tile width
         if (F.tile_order) tile = F.tile_order[tile];
         const unsigned int pix = (unsigned)lane & ((1u << pxl) - 1u);
-        const unsigned int fi = (g << fgl) + ((unsigned)lane >> pxl);
+        const unsigned int fi = frame0 + ((unsigned)lane >> pxl);
         const int x = (int)((tile % (unsigned)F.tiles_x) * 8u + ((sub & ((1u << (3 - swl)) - 1u)) << swl) + (pix & ((1u << swl) - 1u)));
         const int yy = (int)((tile / (unsigned)F.tiles_x) * 8u + ((sub >> (3 - swl)) << swl) + (pix >> swl));
         if (!(x < p.width && yy < F.nrows && fi < nframes_)) return false;
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (F.tile_cost && group_len != 0 && lane == 0) {
                 const uint32_t share = (uint32_t)(((__builtin_readcyclecounter() - wave_t0) >> 6) / group_len);
                 for (unsigned int k = 0; k < group_len; ++k) {
-                    unsigned int t = ((group_base + k) % per_group_) >> fgl;
+                    unsigned int t, sub_, f0_;
+                    (void)decode(group_base + k, t, sub_, f0_);
                     if (F.tile_order) t = F.tile_order[t];
                     atomicAdd(&F.tile_cost[t], share);
                 }
