@@ -10,3 +10,12 @@ int rt_render(struct rt_ctx* c, int a, int b) { return -1; }
 int rt_reset_accum(struct rt_ctx* c) { return -1; }
 int rt_read_accum(struct rt_ctx* c, float* f, size_t n) { return -1; }
 const char* rt_last_error(struct rt_ctx* c) { return "stub"; }
+struct rt_multi;
+int rt_multi_set_params(struct rt_multi* m, const void* p) { return -1; }
+int rt_multi_upload_spheres(struct rt_multi* m, const void* p, int n) { return -1; }
+int rt_multi_upload_triangles(struct rt_multi* m, const void* p, int n) { return -1; }
+int rt_multi_upload_meshinfo(struct rt_multi* m, const void* p, int n) { return -1; }
+int rt_multi_render(struct rt_multi* m, int a, int b) { return -1; }
+int rt_multi_reset_accum(struct rt_multi* m) { return -1; }
+int rt_multi_read_accum(struct rt_multi* m, float* f, size_t n) { return -1; }
+const char* rt_multi_last_error(const struct rt_multi* m) { return "stub"; }

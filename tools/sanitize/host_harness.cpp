@@ -7,6 +7,25 @@ int main(int argc, char** argv) {
             m.OnValidate();
             rthost::SceneBuffers b = m.BuildBuffers();
             printf("%s: %zu spheres %zu triangles %zu chunks\n", argv[i], b.spheres.size(), b.triangles.size(), b.meshInfo.size());
+            // MeshSplitter + GetSubMeshes on meshes without cached chunks: every mesh of the scene re-split from its own triangles
+            size_t resplit = 0;
+            for (rthost::RayTracedMesh& rm : m.meshes) {
+                rthost::Mesh mesh;
+                for (const rthost::MeshChunk& c : rm.localChunks)
+                    for (const rt_triangle& t : c.triangles)
+                        for (int k = 0; k < 3; ++k) {
+                            const float* f = reinterpret_cast<const float*>(&t);        // posA posB posC normalA normalB normalC
+                            mesh.triangles.push_back((int)mesh.vertices.size());
+                            mesh.vertices.push_back({ f[3 * k], f[3 * k + 1], f[3 * k + 2] });
+                            mesh.normals.push_back({ f[9 + 3 * k], f[9 + 3 * k + 1], f[9 + 3 * k + 2] });
+                        }
+                if (mesh.triangles.empty()) continue;
+                mesh.subMeshes.push_back({ 0, (int)mesh.triangles.size() });
+                rthost::RayTracedMesh fresh; fresh.transform = rm.transform; fresh.materials = rm.materials; fresh.sharedMesh = &mesh;
+                fresh.enforceTriangleLimit = false;
+                for (const rthost::MeshChunk& c : fresh.GetSubMeshes()) resplit += c.triangles.size();
+            }
+            printf("%s: %zu triangles through MeshSplitter\n", argv[i], resplit);
         } catch (const std::exception& e) { printf("%s: exception %s\n", argv[i], e.what()); }
     }
     return 0;
