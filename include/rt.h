@@ -197,7 +197,7 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     case is deeper spills the rest to global memory
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order
- *   "frame_batch"     k_trace: frames traced per launch by rt_render (0 = auto: as many as fit 1 GiB, 1 = one per launch)
+ *   "frame_batch"     k_trace: frames traced per launch by rt_render (0 = auto: as many as fit 4 GiB, at most 256; 1 = one per launch)
  *   "lds_stack"       k_trace: traversal-stack entries kept in LDS, deeper ones spill to global memory (0 = all in LDS)
  *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst (default 48)
  *   "node_min"        k_stream: inside a burst the node loop goes on while at least this many lanes hold an internal node (or no

@@ -621,7 +621,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     int batch = 1;
     const bool stream_tiles = stream && c->opt_tile_sync;        // k_stream taking whole tiles: same (frame, tile) items as k_trace
     if ((tile_kernel || stream_tiles || waved) && n_frames > 1 && c->opt_frame_batch != 1) {
-        const size_t budget = (size_t)1 << 30;                                  // <= 1 GiB of per-frame outputs
+        const size_t budget = (size_t)4 << 30;                                  // <= 4 GiB of per-frame outputs (16 frames at 3840x2160)
         const size_t per_frame = c->target_pixels * sizeof(float4);
         batch = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, budget / per_frame));
         if (c->opt_frame_batch > 1) batch = std::min(batch, c->opt_frame_batch);
