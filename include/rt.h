@@ -208,9 +208,10 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "stream_tile"     k_stream: frames interleaved in a wave, as log2: 0 = 8x8 pixels of one frame, 2 = 4x4 pixels x 4 frames of the
  *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)
  *   "device_bvh"      1 = build the BVH on the device (Morton order, PLOC clustering, breadth-first collapse to 4-wide nodes: 100k
- *                     triangles in 1.9 ms, 1M in 4.0 ms), 0 = the host's binned-SAH builder (50 ms / 600 ms, 7-13 % less traversal
+ *                     triangles in 2.0 ms, 1M in 4.3 ms), 0 = the host's binned-SAH builder (50 ms / 600 ms, 5-10 % less traversal
  *                     work per ray), -1 (default) = device for rt_upload_local_meshes (meshes that move), host for world-space uploads
- *   "bvh_radius"      device builder: PLOC search radius, 1..64 (default 16)
+ *   "bvh_radius"      device builder: PLOC search radius of the first rounds, 1..64 (default 8); it doubles once a quarter and again once
+ *                     a sixteenth of the clusters is left; a negative value keeps |value| in every round
  *   "rebuild_percent" on-device geometry pipeline: after a refit, rebuild on the device once the summed internal box area exceeds
  *                     this percentage of its value right after the last build (default 200; 0 = never)
  *   "compact_nodes"   k_trace / k_stream: 1 = traverse the f16 form of the BVH nodes (5 loads per node visit, default), 0 = the

@@ -94,9 +94,11 @@ struct rt_ctx {
     float area_at_build = 0.f;      // sum of internal child-box areas right after the last build (refit quality monitor)
     int opt_device_bvh = -1;        // 1: build the BVH on the device (Morton order + PLOC + collapse), 0: host binned-SAH builder,
                                     // -1: device for the on-device geometry pipeline (meshes that move), host for world-space uploads
-                                    // (a static scene is built once and traced for many frames: the SAH tree costs 7-13 % less
-                                    // traversal work per ray, the device build is 25-150x faster)
-    int opt_bvh_radius = 16;        // device builder: PLOC search radius (8 / 16 / 32: 1.19 / 1.15 / 1.18 x the host tree's work per ray at 1M triangles)
+                                    // (a static scene is built once and traced for many frames: the SAH tree is traced 4-16 % faster,
+                                    // the device build is 25-140x faster)
+    int opt_bvh_radius = 8;         // device builder: PLOC search radius of the first rounds; doubled once a quarter, again once a sixteenth of
+                                    // the clusters is left (negative = that radius in every round).  Work per ray against the host tree at
+                                    // 100k / 1M triangles: 8 -> 1.10 / 1.05, 12 -> 1.10 / 1.09, 16 -> 1.10 / 1.17, fixed 16 -> 1.07 / 1.13
     int opt_rebuild_percent = 200;  // device pipeline: rebuild instead of refit once the internal area exceeds this share of the build's
     int n_cu = 0;
     int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream, 2: k_pool
@@ -999,7 +1001,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
     else if (!std::strcmp(name, "compact_nodes")) c->opt_compact_nodes = value ? 1 : 0;
     else if (!std::strcmp(name, "device_bvh")) { if (value < -1 || value > 1) return fail(c, -2, "device_bvh must be -1 (automatic), 0 or 1"); if (value != c->opt_device_bvh) c->scene_dirty = true; c->opt_device_bvh = value; }
-    else if (!std::strcmp(name, "bvh_radius")) { if (value < 1 || value > rtgb::kMaxRadius) return fail(c, -2, "bvh_radius must be in [1,64]"); if (value != c->opt_bvh_radius) c->scene_dirty = true; c->opt_bvh_radius = value; }
+    else if (!std::strcmp(name, "bvh_radius")) { if (value == 0 || value < -rtgb::kMaxRadius || value > rtgb::kMaxRadius) return fail(c, -2, "bvh_radius must be in [1,64] (negative: the same radius in every round)"); if (value != c->opt_bvh_radius) c->scene_dirty = true; c->opt_bvh_radius = value; }
     else if (!std::strcmp(name, "rebuild_percent")) { if (value < 0 || value > 100000) return fail(c, -2, "rebuild_percent must be in [0,100000] (0 = never rebuild)"); c->opt_rebuild_percent = value; }
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;

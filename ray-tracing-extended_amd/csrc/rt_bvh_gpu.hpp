@@ -421,7 +421,8 @@ struct Result {
 inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, float origin_magnitude, int radius, Workspace& w,
                         rtbvh::Node4* nodes, uint32_t* order, Result& out)
 {
-    radius = std::max(1, std::min(radius, kMaxRadius));
+    const bool widen = radius > 0;              // a negative radius = that radius in every round (A/B of the schedule)
+    radius = std::max(1, std::min(radius < 0 ? -radius : radius, kMaxRadius));
     out = Result();
     if (nt == 0) return hipSuccess;
     const uint32_t nb0 = (nt + kPlocBlock - 1) / kPlocBlock;
@@ -449,7 +450,9 @@ inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, floa
     uint32_t* cin = w.c0.p; uint32_t* cout = w.c1.p;
     while (m > (uint32_t)kPlocBlock) {
         const uint32_t nb = (m + kPlocBlock - 1) / kPlocBlock;
-        hipLaunchKernelGGL(k_ploc_round, dim3(nb), dim3(kPlocBlock), 0, stream, cin, m, nt, w.bmin.p, w.bmax.p, w.child.p, w.ctr.p, w.tmp.p, w.block_count.p, radius);
+        // wider search as the clusters get fewer and larger (the upper levels decide most of a ray's node visits, and cost little)
+        const int r_now = (widen && m <= nt / 16) ? std::min(kMaxRadius, 4 * radius) : (widen && m <= nt / 4) ? std::min(kMaxRadius, 2 * radius) : radius;
+        hipLaunchKernelGGL(k_ploc_round, dim3(nb), dim3(kPlocBlock), 0, stream, cin, m, nt, w.bmin.p, w.bmax.p, w.child.p, w.ctr.p, w.tmp.p, w.block_count.p, r_now);
         hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, stream, w.block_count.p, nb, w.block_offset.p, w.ctr.p);
         hipLaunchKernelGGL(k_ploc_gather, dim3(nb), dim3(kPlocBlock), 0, stream, w.tmp.p, w.block_count.p, w.block_offset.p, cout);
         uint32_t m_next = 0;

@@ -27,10 +27,10 @@ def _render_with(tracer, b, builder, frames=2, counting=False, want_bvh=False, *
         return tracer.read_accum(), tracer.stats()
     finally:
         tracer.set_option("device_bvh", -1)
-        tracer.set_option("bvh_radius", 16)
+        tracer.set_option("bvh_radius", 8)
 
 
-@pytest.mark.parametrize("radius", [1, 16, 64])
+@pytest.mark.parametrize("radius", [1, 8, -16, 64])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_device_built_tree_gives_the_oracles_image(rtx, oracle, tracer, mode, radius):
     b = list(rtx.scenes.mesh_test_scene(96, 64).build_buffers())
