@@ -201,9 +201,11 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "lds_stack"       k_trace: traversal-stack entries kept in LDS, deeper ones spill to global memory (0 = all in LDS)
  *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst (default 48)
  *   "node_min"        k_stream: inside a burst the node loop goes on while at least this many lanes hold an internal node (or no
- *                     lane holds a leaf); below it the leaves are served first (default 6; 1 = classic while-while)
- *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch; a lane that finishes its pixel of one tile moves on to its
- *                     position in the next tile of the group instead of idling until the tile's slowest pixel is done (default 2)
+ *                     lane holds a leaf); below it the leaves are served first (default 10; 1 = classic while-while)
+ *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch while the launch's queue is long; a lane that finishes its pixel of
+ *                     one item moves on to its position in the next instead of idling until the item's slowest pixel is done (default 12)
+ *   "fetch_guide"     k_stream: guided self-scheduling — groups of tiles_per_fetch items while more than fetch_guide groups per wave of
+ *                     the launch are left in the queue, then items_left / (waves x fetch_guide), down to single items (default 4)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
  *   "stream_tile"     k_stream: frames interleaved in a wave, as log2: 0 = 8x8 pixels of one frame, 2 = 4x4 pixels x 4 frames of the
  *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)

@@ -105,11 +105,14 @@ struct rt_ctx {
     int auto_choice = -1; double auto_ms[2] = { -1.0, -1.0 };
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
-    int opt_tiles_per_fetch = 4;    // k_stream: measured best with 2x2 x 16 items (2: 11.89, 3: 12.03, 4: 12.17, 5: 12.04, 8: 11.65 Grays/s)
+    int opt_fetch_guide = 4;        // k_stream: groups of tiles_per_fetch items while more than this many groups per wave are left (then smaller)
+    int opt_tiles_per_fetch = 12;   // k_stream: items a wave reserves per fetch while the queue is long (guided: fewer near the end).  Fixed groups of
+                                    // 2 / 4 / 8: 11.89 / 12.17 / 11.65 Grays/s (the tail grows); guided 4 / 8 / 12 / 16 / 24: 12.35 / 12.55 / 12.60 / 12.61 / 12.60
     int opt_compact_nodes = 1;      // k_trace / k_stream: traverse the f16 form of the nodes (Node4h: 5 loads per visit instead of 7)
     int opt_stream_tile = 4;        // k_stream: log2 of the most frames interleaved in a wave (0: 8x8 pixels x 1 frame, 2: 4x4 x 4, 4: 2x2 x 16)
                                     // measured on the 100k-triangle workload: 10.86 / 11.48 / 11.89 Grays/s; with 4 tiles per fetch 12.17
-    int opt_node_min = 6;           // k_stream: measured best 4..8 on the 100k-triangle workload (+7 % over 1)
+    int opt_node_min = 10;          // k_stream: 4..10 within 0.5 % of each other on the 100k-triangle workload (+7 % over 1); 6 / 8 / 10 on the
+                                    // million-triangle one: 11.72 / 11.83 / 11.90 Grays/s
     int opt_blocks_per_cu = 0;      // 0: occupancy API
     int opt_full_sort = 0;          // 1: sort all four children; 0: nearest first only (measured +1 %)
     int opt_tile_lpt = 1;           // k_trace: dispatch the costliest tiles first, using the costs measured by the previous launch
@@ -590,7 +593,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
     A.total_pixels = (unsigned int)ntiles * 64u;
     A.tile_sync = c->opt_tile_sync;
-    A.tiles_per_fetch = std::max(1, std::min(16, c->opt_tiles_per_fetch));
+    A.tiles_per_fetch = std::max(1, std::min(64, c->opt_tiles_per_fetch));
+    A.guide_div = 1;
     A.node_min = std::max(1, std::min(64, c->opt_node_min));
     rtk::PoolArgs PA{};
     PA.total_pixels = A.total_pixels;
@@ -658,11 +662,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
             if (c->opt_stream_tile >= 4) { A.n16 = rem / 16; rem -= A.n16 * 16; }
             if (c->opt_stream_tile >= 2) { A.n4 = rem / 4; rem -= A.n4 * 4; }
             A.n1 = rem;
-            // big groups only while every wave still gets at least ~16 of them: a single frame has 8 tiles per wave in all, and
-            // groups of 4 would end the launch on a few waves (measured: 38.7 ms instead of 24 ms for one 1080p frame; one eighth of
-            // the image x 20 frames, 20 items per wave: 3.21 ms per frame with groups of 2, 2.86 with single items)
-            const size_t items = (size_t)ntiles * (size_t)nb, waves = (size_t)grid * rtk::kWavesPerBlock;
-            A.tiles_per_fetch = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, std::min(16, c->opt_tiles_per_fetch)), items / (waves * 16)));
+            // groups shrink towards the end of the launch (k_stream: guided self-scheduling): up to tiles_per_fetch items per fetch
+            // while more than guide x (waves of the launch) x that many items are left
+            A.tiles_per_fetch = std::max(1, std::min(64, c->opt_tiles_per_fetch));
+            A.guide_div = std::max(1, grid * rtk::kWavesPerBlock * std::max(1, c->opt_fetch_guide));
         }
         F.frame = first_frame + i;
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
@@ -996,7 +999,8 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "tile_w_log2")) { if (value < 0 || value > 6) return fail(c, -2, "tile_w_log2 must be in [0,6]"); c->opt_tile_w_log2 = value; }
     else if (!std::strcmp(name, "tile_lpt")) { c->opt_tile_lpt = value ? 1 : 0; c->tile_order_valid = false; }
     else if (!std::strcmp(name, "frame_batch")) { if (value < 0 || value > 1024) return fail(c, -2, "frame_batch must be in [0,1024]"); c->opt_frame_batch = value; }
-    else if (!std::strcmp(name, "tiles_per_fetch")) { if (value < 1 || value > 16) return fail(c, -2, "tiles_per_fetch must be in [1,16]"); c->opt_tiles_per_fetch = value; }
+    else if (!std::strcmp(name, "fetch_guide")) { if (value < 1 || value > 64) return fail(c, -2, "fetch_guide must be in [1,64]"); c->opt_fetch_guide = value; }
+    else if (!std::strcmp(name, "tiles_per_fetch")) { if (value < 1 || value > 64) return fail(c, -2, "tiles_per_fetch must be in [1,64]"); c->opt_tiles_per_fetch = value; }
     else if (!std::strcmp(name, "node_min")) { if (value < 1 || value > 64) return fail(c, -2, "node_min must be in [1,64]"); c->opt_node_min = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;
     else if (!std::strcmp(name, "compact_nodes")) c->opt_compact_nodes = value ? 1 : 0;

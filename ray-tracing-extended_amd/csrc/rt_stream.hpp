@@ -27,8 +27,10 @@ struct StreamArgs {
     int shade_threshold;        // lanes waiting for SHADE that trigger it
     unsigned int total_pixels;  // tiles_x * tiles_y * 64 (tile-major enumeration, padded)
     int node_min;               // the node loop of a burst goes on while at least this many lanes hold an internal node (or no lane holds a leaf)
-    int tiles_per_fetch;        // tile_sync: a wave reserves this many consecutive work items at a time; a lane that finishes its
+    int tiles_per_fetch;        // tile_sync: a wave reserves up to this many consecutive work items at a time; a lane that finishes its
                                 // pixel of one moves on to its position in the next without waiting for the slower lanes
+    int guide_div;              // ... as long as more than tiles_per_fetch * guide_div items are left in the launch's queue; below
+                                // that the groups shrink to items_left / guide_div, down to single items (= waves of the launch x a factor)
     int tile_sync;              // 1: a wave takes a whole 8x8 tile at a time (coherent lanes), 0: lanes refill pixel by pixel
     int n16, n4, n1;            // tile_sync: the launch's frames as n16 groups of 16, then n4 groups of 4, then n1 single frames.  A work
                                 // item is a sub-tile of 2x2 / 4x4 / 8x8 pixels in the 16 / 4 / 1 frames of a group: lane = (frame of the
@@ -143,10 +145,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     atomicAdd(&F.tile_cost[t], share);
                 }
             }
-            const unsigned int K = (unsigned)A.tiles_per_fetch;
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(F.tile_counter, 64u * K);
+            // guided self-scheduling: groups of up to tiles_per_fetch items while plenty of work is left (lanes flow from one item to
+            // the next instead of idling behind the item's slowest pixel), single items near the end of the launch (balance)
+            unsigned int base = 0, K = 1;
+            if (lane == 0) {
+                const unsigned int handed = __hip_atomic_load(F.tile_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6;
+                const unsigned int rem = nitems_ > handed ? nitems_ - handed : 0u;
+                K = min((unsigned)A.tiles_per_fetch, max(1u, rem / (unsigned)A.guide_div));
+                base = atomicAdd(F.tile_counter, 64u * K);
+            }
             base = __builtin_amdgcn_readfirstlane(base);
+            K = __builtin_amdgcn_readfirstlane(K);
             group_base = base >> 6;
             if (group_base >= nitems_) break;
             group_len = min(K, nitems_ - group_base);

@@ -114,7 +114,7 @@ def test_node_loop_cap_does_not_change_the_image(rtx, oracle, tracer, node_min):
         tracer.render_counting(2, 2)
         st = tracer.stats()
     finally:
-        tracer.set_option("node_min", 6)
+        tracer.set_option("node_min", 10)
     want, want_last, cnt = oracle.render(*b, 2, 2)
     assert_bitwise(got_last, want_last, f"node_min={node_min}: last frame")
     assert_bitwise(got, want, f"node_min={node_min}: accum")
@@ -292,7 +292,7 @@ def test_tile_groups_multi_frame(rtx, oracle, tracer, size, k):
         acc, last = run_gpu(tracer, b, 1, 3, kernel=1)
         st = tracer.stats()
     finally:
-        tracer.set_option("tiles_per_fetch", 4)
+        tracer.set_option("tiles_per_fetch", 12)
     want, want_last, cnt = oracle.render(*b, 1, 3)
     assert_bitwise(last, want_last, f"{size} k={k}: last frame")
     assert_bitwise(acc, want, f"{size} k={k}: accum")
