@@ -100,13 +100,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // cut into A.n16 groups of 16, then A.n4 groups of 4, then A.n1 single frames; all their items sit in one queue, so whatever the
     // frame count the launch has one tail.
     const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-    const unsigned int items16_ = (unsigned)A.n16 * (ntiles_ << 4), items4_ = (unsigned)A.n4 * (ntiles_ << 2);
-    const unsigned int nitems_ = items16_ + items4_ + (unsigned)A.n1 * ntiles_;
+    const unsigned int items1_ = (unsigned)A.n1 * ntiles_, items4_ = (unsigned)A.n4 * (ntiles_ << 2);
+    const unsigned int nitems_ = items1_ + items4_ + (unsigned)A.n16 * (ntiles_ << 4);
     const unsigned int nframes_ = (unsigned)(A.n16 * 16 + A.n4 * 4 + A.n1);
-    // item -> its 8x8 tile (before the costliest-first permutation), sub-tile, first frame and log2 of its frame count
+    // item -> its 8x8 tile (before the costliest-first permutation), sub-tile, first frame and log2 of its frame count.  The queue
+    // holds the single frames first, then the groups of 4, then the groups of 16 (frames n16*16 + n4*4 .., n16*16 .., 0 ..): the
+    // launch ends on the cheap tiles of its most efficient items.
     auto decode = [&](unsigned int item, unsigned int& tile, unsigned int& sub, unsigned int& frame0) -> int {
-        int fgl = 4; unsigned int fbase = 0;
-        if (item >= items16_) { item -= items16_; fgl = 2; fbase = (unsigned)A.n16 * 16u; if (item >= items4_) { item -= items4_; fgl = 0; fbase += (unsigned)A.n4 * 4u; } }
+        int fgl = 0; unsigned int fbase = (unsigned)A.n16 * 16u + (unsigned)A.n4 * 4u;
+        if (item >= items1_) { item -= items1_; fgl = 2; fbase = (unsigned)A.n16 * 16u; if (item >= items4_) { item -= items4_; fgl = 4; fbase = 0u; } }
         const unsigned int per_group = ntiles_ << fgl;
         const unsigned int g = item / per_group, r = item - g * per_group;
         tile = r >> fgl; sub = r & ((1u << fgl) - 1u); frame0 = fbase + (g << fgl);
