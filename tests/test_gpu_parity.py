@@ -243,6 +243,27 @@ def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene):
     assert not np.array_equal(pcg, acc)
 
 
+def test_philox_mode_with_frame_interleaved_items(rtx, oracle, tracer):
+    """The counter-based mode through k_stream's frame-interleaved items: 21 frames in one launch (one group of 16, one of 4, one
+    single frame), f16 and f32 nodes — the accumulated image and the ray count are the oracle twin's."""
+    params, spheres, tris, infos = rtx.scenes.mesh_test_scene(80, 56).build_buffers()
+    params = params.copy()
+    params["rngMode"] = 1
+    b = (params, spheres, tris, infos)
+    want, want_last, cnt = oracle.render(*b, 0, 21)
+    for compact in (1, 0):
+        tracer.set_option("compact_nodes", compact)
+        try:
+            acc, last = run_gpu(tracer, b, 0, 21, kernel=1)
+            st = tracer.stats()
+        finally:
+            tracer.set_option("compact_nodes", 1)
+        assert st["lastFramesPerLaunch"] == 21 and st["lastFramesInterleaved"] == 16
+        assert_bitwise(last, want_last, f"philox, 21 interleaved frames, compact_nodes={compact}: last frame")
+        assert_bitwise(acc, want, f"philox, 21 interleaved frames, compact_nodes={compact}: accum")
+        assert st["rays"] == cnt["rays"]
+
+
 def test_multi_frame_launch_equals_frame_by_frame(rtx, oracle, tracer):
     """rt_render(first, n) traces n frames per k_trace launch (work items = (frame, tile)) and accumulates them in order
     afterwards; the result equals n single-frame launches and the oracle (sun at 200x: the clamped running average is
