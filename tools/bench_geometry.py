@@ -18,6 +18,9 @@ BYTES_PER_TRI = 72 + 72 + 4 + 72 + 72 + 96 + 8 + 72     # transform R/W, bounds 
 def main():
     out = []
     tr = rtx.Tracer(0)
+    opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+    for k, v in opts.items():
+        tr.set_option(k, int(v))
     for name, gen in (("config3", rtx.scenes.config3), ("config5", rtx.scenes.config5)):
         mgr = gen(256, 144)
         t0 = time.perf_counter()
@@ -48,7 +51,7 @@ def main():
         nt = len(tris)
         nodes = tr.stats()["numBvhNodes"]
         alg = nt * BYTES_PER_TRI + nodes * 128 * 3
-        out.append({"workload": name, "triangles": nt, "meshes": len(mgr.meshes), "bvh_nodes": nodes,
+        out.append({"workload": name, "options": opts, "triangles": nt, "meshes": len(mgr.meshes), "bvh_nodes": nodes,
                     "device_geometry_ms": round(gms, 4), "device_wall_ms_incl_40B_per_mesh_upload": round(float(np.median([m[1] for m in ms])), 3),
                     "algorithmic_bytes": alg, "achieved_GBps": round(alg / (gms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg / (gms * 1e-3) / 8e12, 4),
                     "reference_way_host_transform_s": round(t_marshal, 3), "reference_way_upload_plus_bvh_build_s": round(t_upload_build_render, 3)})
