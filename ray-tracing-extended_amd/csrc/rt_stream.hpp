@@ -222,7 +222,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         ++bounce;
                         if (bounce > p.maxBounceCount) path_done = true;               // loop bound :305
                     } else {
+#ifndef RT_DIAG_IDLE
                         phase_tick<COUNT>(cnt, 3);
+#endif
                         light = light + environment_light(p, d) * rayColour;           // :346-347
                         path_done = true;
                     }
@@ -285,7 +287,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 if (mode == kModeShade) {
                     if (need_ray) {
                         // ---- frag :364-382
+#ifndef RT_DIAG_IDLE
                         phase_tick<COUNT>(cnt, 4);
+#endif
                         const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
                         const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
@@ -327,6 +331,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     const int nAtNode = __popcll(ballot2_(mode == kModeTrav, (int)cur >= 0));
                     if (nAtNode == 0) break;
                     if (nAtNode < A.node_min && ballot2_(mode == kModeTrav, (int)cur < 0) != 0) break;   // few descenders: serve the leaves first
+#ifdef RT_DIAG_IDLE      // diagnostic build only: what the lanes that sit out a node step are waiting for (counters 3 / 4 re-used)
+                    if (COUNT) {
+                        if (mode == kModeTrav && (int)cur < 0) cnt.phase_lanes[3]++;          // holds a leaf
+                        if (mode == kModeShade) cnt.phase_lanes[4]++;                          // query complete, waits for SHADE
+                        if (lane == 0) { cnt.phase_execs[3]++; cnt.phase_execs[4]++; }
+                    }
+#endif
                     if (mode == kModeTrav && (int)cur >= 0) {
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
