@@ -187,9 +187,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- setup (untimed): upload, BVH build, and the library's three calibration frames (tile costs for its costliest-first
+    # ---- setup (untimed): upload, BVH build, and the library's calibration frames (tile costs for its costliest-first
     # tile order; k_trace vs k_stream timing for its automatic kernel choice) — then the W warmup steps
-    tr.render(0, 3)
+    tr.render(0, 4)
     tr.reset_accum()
     tr.render(0, max(args.warmup, 0))
     gather = rtx.distributed.gather_image_banded if banded else rtx.distributed.gather_image

@@ -193,7 +193,7 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "bvh_bins", "bvh_cost_exp", "bvh_reinsert"   BVH builder: SAH bins per axis (32); exponent, in percent, of the triangle
  *                     count in the SAH's subtree-cost model (100); passes of insertion-based optimisation of the binary tree (0:
  *                     measured -3 % node visits per ray but no fewer wave-level steps)
- *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (37 = four workgroups per CU); a BVH whose worst
+ *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (31 = five workgroups per CU); a BVH whose worst
  *                     case is deeper spills the rest to global memory
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order

@@ -103,6 +103,7 @@ struct rt_ctx {
     int n_cu = 0;
     int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream, 2: k_pool
     int auto_choice = -1; double auto_ms[2] = { -1.0, -1.0 };
+    unsigned variants_launched = 0;     // kernel variants that have run at least once in this context (automatic choice: see launch_frames)
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
     int opt_fetch_guide = 4;        // k_stream: groups of tiles_per_fetch items while more than this many groups per wave are left (then smaller)
@@ -121,7 +122,7 @@ struct rt_ctx {
     int opt_bvh_reinsert = 0;       // BVH builder: insertion-based optimisation passes
     int opt_bvh_bins = 32, opt_bvh_cost_exp = 100;   // BVH builder: SAH bins per axis; exponent (percent) of the count in the SAH cost model
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
-    int opt_stream_stack = 37;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory
+    int opt_stream_stack = 31;      // k_stream: stack entries per lane kept in LDS (31 = five workgroups per CU); deeper BVHs spill the rest to global memory
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
     int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
@@ -556,7 +557,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const bool tile_kernel = !stream && !pooled && !waved && var != Variant::Flat;   // k_trace, PCG or Philox
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     if (tile_kernel) F.stack_cap = std::min(F.stack_cap, 64);        // a very deep tree spills past 64 entries instead of overflowing the LDS
-    // k_stream: at most opt_stream_stack entries per lane in LDS (37 = four workgroups per CU); a deeper worst case spills
+    // k_stream: at most opt_stream_stack entries per lane in LDS (31 = five workgroups per CU); a deeper worst case spills
     const bool stream_spill = stream && F.stack_cap > c->opt_stream_stack;
     if (stream_spill) F.stack_cap = c->opt_stream_stack;
     F.full_sort = c->opt_full_sort;
@@ -584,9 +585,11 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     // k_pool waves own 128 pixel slots each: two tiles' worth
     // ... and k_wave waves 256: four tiles' worth (of any frame of the launch)
     const int frames_hint = waved ? std::max(1, std::min(n_frames, 8)) : 1;
+    // work items of a multi-frame launch = tiles x frames: a thin strip (one rank of eight: 4,080 tiles) still fills every resident wave
+    const size_t frames_in_queue = (stream && c->opt_tile_sync && c->opt_frame_batch != 1) ? (size_t)std::max(1, std::min(n_frames, 64)) : 1;
     const int want = pooled ? (ntiles + 2 * rtk::kWavesPerBlock - 1) / (2 * rtk::kWavesPerBlock)
                    : waved ? (int)(((size_t)ntiles * frames_hint + 4 * rtk::kWavesPerBlock - 1) / (4 * rtk::kWavesPerBlock))
-                            : (ntiles + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock;
+                            : (int)std::min<size_t>(((size_t)ntiles * frames_in_queue + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock, (size_t)1 << 20);
     if (c->opt_blocks_per_cu > 0) per_cu = std::min(per_cu, c->opt_blocks_per_cu);
     const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
     rtk::StreamArgs A{};
@@ -778,8 +781,13 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         if (r) return r;
         add();
         if (c->target_pixels == 0) { done += count; continue; }
+        // a kernel variant's very first launch in a context also pays its one-off set-up (code upload, the scratch ring of
+        // k_stream): that frame is rendered like any other but not used as the timing
+        const int variant = kernel * 4 + (c->params.rngMode == RT_RNG_PHILOX ? 2 : 0) + (c->opt_compact_nodes ? 1 : 0);
+        const bool first_use = !((c->variants_launched >> variant) & 1u);
+        c->variants_launched |= 1u << variant;
         if (probing) {
-            c->auto_ms[kernel] = c->stats.lastKernelMs;
+            if (!first_use) c->auto_ms[kernel] = c->stats.lastKernelMs;
             if (c->auto_ms[0] >= 0 && c->auto_ms[1] >= 0) c->auto_choice = (c->stats.numBvhNodes > 0 && c->auto_ms[1] < c->auto_ms[0]) ? 1 : 0;
         }
         done += count;

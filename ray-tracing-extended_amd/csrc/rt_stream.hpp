@@ -42,7 +42,13 @@ struct StreamArgs {
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
 template <bool COUNT, bool PHILOX = false, bool H = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
+// Five waves per SIMD (96 VGPRs, 15 dwords of scratch in the SHADE phase, LDS stack of <= 31 entries per lane so that five workgroups
+// fit a CU): the kernel hides its memory and LDS latencies with resident waves — 3 / 4 / 5 / 6 waves per SIMD give 10.4 / 12.4 / 12.9 /
+// 11.2 Grays/s on the 100k-triangle workload (6 waves = 80 VGPRs spill 31 dwords), 11.85 -> 12.75 on the million-triangle one.
+#ifndef RT_STREAM_WAVES
+#define RT_STREAM_WAVES 5
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREAM_WAVES, RT_STREAM_WAVES))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -163,7 +163,7 @@ def test_stream_stack_spill_does_not_change_the_image(rtx, tracer, stream_stack)
         got, got_last = run_gpu(tracer, b, 2, 2, kernel=1)
         rays = tracer.stats()["rays"]
     finally:
-        tracer.set_option("stream_stack", 37)
+        tracer.set_option("stream_stack", 31)
     assert_bitwise(got_last, ref_last, f"stream(stack={stream_stack}) vs tile kernel, last frame")
     assert_bitwise(got, ref, f"stream(stack={stream_stack}) vs tile kernel, accum")
     assert rays == rays_ref
@@ -290,7 +290,8 @@ def test_multi_frame_launch_equals_frame_by_frame(rtx, oracle, tracer):
 
 def test_automatic_kernel_choice_is_transparent(rtx, oracle, tracer):
     """kernel = -1 (default): frames 0..5 are traced by a mix of k_trace / k_stream launches while the library measures
-    which is faster; the image is the oracle's, and the choice is made after three frames."""
+    which is faster; the image is the oracle's, and the choice is made after three or four frames (a variant's very first launch
+    in a context is not used as its timing)."""
     b = rtx.scenes.mesh_test_scene(96, 64).build_buffers()
     acc, last = run_gpu(tracer, b, 0, 6, kernel=-1)
     st = tracer.stats()
