@@ -231,6 +231,8 @@ def main():
     compact = int(opts.get("compact_nodes", 1)) != 0
     kernel_name = kernel_names.get(chosen, "k_trace<false,false,true,{H}>" if args.rng == "philox" else "k_trace<false,false,false,{H}>").replace(
         "{H}", "true" if compact else "false")
+    if len(tris) == 0 and kernel_name.startswith("k_trace"):
+        kernel_name = kernel_name.replace(",true>", ",false,6>").replace(",false>", ",false,6>")      # spheres only: the six-waves-per-SIMD instantiation
     if not args.no_roofline:
         tr.reset_accum()
         tr.render_counting(0, args.steps)

@@ -576,6 +576,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
                    : pooled ? (counting ? (const void*)rtk::k_pool<true> : (const void*)rtk::k_pool<false>)
                    : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
                    : stream ? dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_stream<decltype(C)::value, decltype(P)::value, decltype(H)::value>; })
+                   : c->n_nodes == 0      // spheres only: the instantiation compiled for six waves per SIMD
+                            ? dispatch3(counting, philox, false, [](auto C, auto P, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, false, 6>; })
                             : dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, decltype(H)::value>; });
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
