@@ -14,6 +14,33 @@ import rtx_pkg
 rtx = rtx_pkg.load()
 
 
+def tree_shape(f32):
+    """Levels, mean / max leaf depth weighted by triangles, and mean children per node of a read-back BVH4 (rt_read_bvh f32 form)."""
+    refs = f32[:, 24:28]
+    n = len(refs)
+    depth = np.zeros(n, np.int32)
+    order = [0]
+    level = [0]
+    d = 0
+    leaf_depth_sum, leaf_tris, max_leaf_depth = 0, 0, 0
+    while level:
+        nxt = []
+        for i in level:
+            for c in refs[i]:
+                if c == 0xFFFFFFFF:
+                    continue
+                if c & 0x80000000:
+                    k = int(c & 3) + 1
+                    leaf_depth_sum += (d + 1) * k; leaf_tris += k; max_leaf_depth = max(max_leaf_depth, d + 1)
+                else:
+                    nxt.append(int(c))
+        level = nxt
+        d += 1
+    used = (refs != 0xFFFFFFFF).sum()
+    return {"levels": d, "mean_leaf_depth": round(leaf_depth_sum / max(leaf_tris, 1), 2), "max_leaf_depth": max_leaf_depth,
+            "children_per_node": round(float(used) / n, 3)}
+
+
 def main():
     out = []
     configs = [a for a in sys.argv[1:] if "=" not in a] or ["config3", "config5"]
@@ -55,10 +82,11 @@ def main():
             tr.render_counting(0, 1)
             st = tr.stats()
             images[builder] = tr.read_last_frame()
+            shape = tree_shape(tr.read_bvh()[0]) if len(tris) <= 200000 else {}
             rec = {"workload": name, "builder": builder, "options": opts, "triangles": int(len(tris)), "bvh_nodes": st["numBvhNodes"], "max_stack": st["bvhMaxStack"], "internal_area": st["bvhInternalArea"],
                    "build_ms": [round(t[0], 3) for t in times], "upload_plus_build_wall_ms": [round(t[1], 2) for t in times],
                    "nodes_per_ray": round(st["nodeVisits"] / st["rays"], 3), "tris_per_ray": round(st["triTests"] / st["rays"], 3),
-                   "rays": st["rays"]}
+                   "rays": st["rays"], "shape": shape}
             rec["nodes_plus_tris_per_ray"] = round(rec["nodes_per_ray"] + rec["tris_per_ray"], 3)
             out.append(rec)
             tr.close()
