@@ -176,6 +176,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
 
         if (nShade >= A.shade_threshold || nTrav == 0) {
             // ================================ SHADE ================================
+            // Wave priority: a wave in a traversal burst alternates short VALU runs with loads it then waits for, a wave in SHADE is
+            // one long VALU stream.  Traversing waves get the issue slots first (s_setprio 1), so their loads are in flight while the
+            // shading waves fill the gaps: +4.5 % / +3.3 % on the two triangle workloads (0/0: 12.86, trav 1 / shade 0: 13.44,
+            // trav 0 / shade 1: 12.91, node loop 2 / leaves 1 / shade 0: 13.44 Grays/s).
+            __builtin_amdgcn_s_setprio(0);
             if (mode == kModeShade) {
                 bool need_ray = fresh;                  // a camera ray must be generated
                 fresh = false;
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             }
         } else {
             // ================================ TRAVERSAL BURST ================================
+            __builtin_amdgcn_s_setprio(1);
             // while-while over the lanes in flight: node steps until no lane holds an internal node, then every lane
             // tests its whole leaf.  The burst ends when all queries are complete, or as soon as `shade_threshold`
             // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
