@@ -5,7 +5,7 @@
 // before shading them: the wave pays for the longest traversal in it (measured on the 100k-triangle workload: 24 node
 // steps executed per 9 needed) and for the slowest pixel of its tile.  Here
 //   * traversal is *resumable*: a while-while burst ends as soon as `shade_threshold` lanes hold a complete query; the
-//     stragglers keep cur / sp / best hit / slab constants in registers, sit out the SHADE pass, and continue in the
+//     stragglers keep cur / top / best hit / slab constants in registers, sit out the SHADE pass, and continue in the
 //     next burst beside the other lanes' new rays — the wave no longer waits for its longest ray;
 //   * inside a burst the node loop hands over to the leaf phase once fewer than `node_min` lanes still hold an internal
 //     node (they wait one leaf phase) instead of running until the last descender reaches a leaf;
@@ -41,6 +41,21 @@ struct StreamArgs {
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
+// The kernel's argument segment as one struct, and a *fresh* view of it.  The persistent loop below has three regions (work-item
+// fetch, SHADE, traversal burst) that need different arguments; read through the kernel's own parameters they are all loop
+// invariants, the compiler keeps every one of them in SGPRs across the whole loop, runs out (86 SGPRs spilled to VGPR lanes) and
+// pays a VALU v_readlane_b32 for each use — on the kernel's binding port.  A region that starts with fresh_args() re-reads what it
+// needs from the kernarg segment with scalar loads instead (the pointer goes through an empty asm, so nothing read through it can
+// be hoisted out of the region), and the values die with the region.
+struct StreamKernArgs { DeviceScene S; FrameArgs F; StreamArgs A; };
+static_assert(alignof(DeviceScene) <= 8 && alignof(FrameArgs) <= 8 && alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
+__device__ __forceinline__ const StreamKernArgs& fresh_args()
+{
+    auto kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const StreamKernArgs*)(const char*)kp;
+}
+
 template <bool COUNT, bool PHILOX = false, bool H = false>
 // Five waves per SIMD (96 VGPRs, 15 dwords of scratch in the SHADE phase, LDS stack of <= 31 entries per lane so that five workgroups
 // fit a CU): the kernel hides its memory and LDS latencies with resident waves — 3 / 4 / 5 / 6 waves per SIMD give 10.4 / 12.4 / 12.9 /
@@ -58,32 +73,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
     // resident whatever the tree depth.
     const int cap = F.stack_cap;
     uint32_t* const gstk = F.gstack ? F.gstack + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
-    int sp = 0;
+    // The stack pointer is the LDS byte address of the next free entry of this lane's column (entries 256 bytes apart): a push is a
+    // ds_write at `top` and a select between top and top + 256 — no entry index to shift and add to a base.  With a global spill
+    // part, `top` runs past the LDS part as a number only; (top - stk0) >> 8 is the entry index.
+    using lds_u32 = __attribute__((address_space(3))) uint32_t;
+    const uint32_t stk0 = (uint32_t)(uintptr_t)(lds_u32*)stk;
+    uint32_t top = stk0;
+    auto slot = [](uint32_t a) -> lds_u32& { return *reinterpret_cast<lds_u32*>((uintptr_t)a); };
+    const uint32_t capb = (uint32_t)cap << 8;
     // pop: plain ds_read when nothing can spill (wave-uniform test); otherwise an LDS read from a clamped slot, replaced by
     // the global entry for the rare lane above the LDS part (a select between the two address spaces would turn every pop
     // into a flat load)
     auto pop = [&]() -> uint32_t {
-        --sp;
-        if (gstk == nullptr) return stk[sp * 64];
-        uint32_t v = stk[min(sp, cap - 1) * 64];
+        top -= 256u;
+        if (gstk == nullptr) return slot(top);
+        const uint32_t depth = top - stk0;
+        uint32_t v = slot(stk0 + min(depth, capb - 256u));
         asm volatile("" : "+v"(v));          // keep this a ds_read: do not fold it into a pointer select with the load below
-        if (sp >= cap) v = gstk[(size_t)(sp - cap) * F.gstack_stride];
+        if (depth >= capb) v = gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride];
         return v;
     };
     Counters cnt = {};
-    const rt_params& p = F.p;
-    const float* M = p.camLocalToWorld;
-    const uint32_t W = (uint32_t)p.width;
-    const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48
-    const float omw = 1.0f - weight;
     const float INF = __builtin_inff();
-
-    Camera cam;
-    cam.W = (float)W;
-    cam.right = rtm::mk(M[0], M[4], M[8]);
-    cam.up    = rtm::mk(M[1], M[5], M[9]);
-    cam.pos   = ld3(p.worldSpaceCameraPos);
-    cam.focusPoint = rtm::mk(0.f, 0.f, 0.f);
 
     // ---- per-lane state -------------------------------------------------------------------------------------
     uint32_t mode = A.tile_sync ? kModeWait : kModeShade;   // every lane starts by asking for a pixel (or the wave for a tile)
@@ -105,14 +116,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
     // Work items: frame group (16, 4 or 1 frames) x 8x8 tile (costliest first) x sub-tile of the tile.  The frames of a launch are
     // cut into A.n16 groups of 16, then A.n4 groups of 4, then A.n1 single frames; all their items sit in one queue, so whatever the
     // frame count the launch has one tail.
-    const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-    const unsigned int items1_ = (unsigned)A.n1 * ntiles_, items4_ = (unsigned)A.n4 * (ntiles_ << 2);
-    const unsigned int nitems_ = items1_ + items4_ + (unsigned)A.n16 * (ntiles_ << 4);
-    const unsigned int nframes_ = (unsigned)(A.n16 * 16 + A.n4 * 4 + A.n1);
+    // (the lambdas take the region's view of the arguments: all of this is scalar arithmetic)
     // item -> its 8x8 tile (before the costliest-first permutation), sub-tile, first frame and log2 of its frame count.  The queue
     // holds the single frames first, then the groups of 4, then the groups of 16 (frames n16*16 + n4*4 .., n16*16 .., 0 ..): the
     // launch ends on the cheap tiles of its most efficient items.
-    auto decode = [&](unsigned int item, unsigned int& tile, unsigned int& sub, unsigned int& frame0) -> int {
+    auto decode = [](const FrameArgs& F, const StreamArgs& A, unsigned int item, unsigned int& tile, unsigned int& sub, unsigned int& frame0) -> int {
+        const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
+        const unsigned int items1_ = (unsigned)A.n1 * ntiles_, items4_ = (unsigned)A.n4 * (ntiles_ << 2);
         int fgl = 0; unsigned int fbase = (unsigned)A.n16 * 16u + (unsigned)A.n4 * 4u;
         if (item >= items1_) { item -= items1_; fgl = 2; fbase = (unsigned)A.n16 * 16u; if (item >= items4_) { item -= items4_; fgl = 4; fbase = 0u; } }
         const unsigned int per_group = ntiles_ << fgl;
@@ -120,9 +130,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         tile = r >> fgl; sub = r & ((1u << fgl) - 1u); frame0 = fbase + (g << fgl);
         return fgl;
     };
-    auto start_pixel = [&](unsigned int item) -> bool {
+    auto start_pixel = [&](const FrameArgs& F, const StreamArgs& A, unsigned int item) -> bool {
+        const rt_params& p = F.p;
+        const uint32_t W = (uint32_t)p.width;
+        const unsigned int nframes_ = (unsigned)(A.n16 * 16 + A.n4 * 4 + A.n1);
         unsigned int tile, sub, frame0;
-        const int fgl = decode(item, tile, sub, frame0);
+        const int fgl = decode(F, A, item, tile, sub, frame0);
         const int pxl = 6 - fgl, swl = pxl >> 1;              // log2 of: pixels per sub-tile, sub-tile width
         if (F.tile_order) tile = F.tile_order[tile];
         const unsigned int pix = (unsigned)lane & ((1u << pxl) - 1u);
@@ -144,11 +157,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
+            const StreamKernArgs& KA = fresh_args();
+            const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
+            const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
+            const unsigned int nitems_ = (unsigned)A.n1 * ntiles_ + (unsigned)A.n4 * (ntiles_ << 2) + (unsigned)A.n16 * (ntiles_ << 4);
             if (F.tile_cost && group_len != 0 && lane == 0) {
                 const uint32_t share = (uint32_t)(((__builtin_readcyclecounter() - wave_t0) >> 6) / group_len);
                 for (unsigned int k = 0; k < group_len; ++k) {
                     unsigned int t, sub_, f0_;
-                    (void)decode(group_base + k, t, sub_, f0_);
+                    (void)decode(F, A, group_base + k, t, sub_, f0_);
                     if (F.tile_order) t = F.tile_order[t];
                     atomicAdd(&F.tile_cost[t], share);
                 }
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             group_len = min(K, nitems_ - group_base);
             wave_t0 = __builtin_readcyclecounter();
             kidx = 0;
-            while (kidx < group_len && !start_pixel(group_base + kidx)) ++kidx;
+            while (kidx < group_len && !start_pixel(F, A, group_base + kidx)) ++kidx;
             if (kidx < group_len) { fresh = true; mode = kModeShade; }
             continue;
         }
@@ -181,6 +198,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             // shading waves fill the gaps: +4.5 % / +3.3 % on the two triangle workloads (0/0: 12.86, trav 1 / shade 0: 13.44,
             // trav 0 / shade 1: 12.91, node loop 2 / leaves 1 / shade 0: 13.44 Grays/s).
             __builtin_amdgcn_s_setprio(0);
+            const StreamKernArgs& KA = fresh_args();
+            const DeviceScene& S = KA.S; const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
+            const rt_params& p = F.p;
+            const float* M = p.camLocalToWorld;
+            const uint32_t W = (uint32_t)p.width;
             if (mode == kModeShade) {
                 bool need_ray = fresh;                  // a camera ray must be generated
                 fresh = false;
@@ -249,6 +271,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             const size_t pi = (size_t)ly * W + (uint32_t)px;
                             F.out_frame[(size_t)wave_fi * F.frame_stride + pi] = make_float4(cx, cy, cz, 1.0f);
                             if (F.frames_in_launch <= 1) {
+                                const float weight = 1.0f / (float)(F.frame + 1);              // Accumulate.shader:48
+                                const float omw = 1.0f - weight;
                                 const float4 prev = F.accum[pi];
                                 float4 acc;
                                 acc.x = rtm::saturate(prev.x * omw + cx * weight);
@@ -261,7 +285,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             if (A.tile_sync) {
                                 // on to this lane's position in the next tile of the wave's group; idle only when the group is done
                                 ++kidx;
-                                while (kidx < group_len && !start_pixel(group_base + kidx)) ++kidx;
+                                while (kidx < group_len && !start_pixel(F, A, group_base + kidx)) ++kidx;
                                 if (kidx < group_len) need_ray = true; else mode = kModeWait;
                             }
                         } else need_ray = true;
@@ -301,6 +325,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
 #ifndef RT_DIAG_IDLE
                         phase_tick<COUNT>(cnt, 4);
 #endif
+                        Camera cam;
+                        cam.W = (float)W;
+                        cam.right = rtm::mk(M[0], M[4], M[8]);
+                        cam.up    = rtm::mk(M[1], M[5], M[9]);
+                        cam.pos   = ld3(p.worldSpaceCameraPos);
                         const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
                         const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
@@ -327,7 +356,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         const bool traceable = ray_traceable(o, d, a);      // NaN / zero-direction rays are complete as they stand
                         if (S.nn > 0 && traceable) {
                             slab = make_slab<H>(o, d);                                  // RayBoundingBox :179
-                            cur = 0; sp = 0; mode = kModeTrav;
+                            cur = 0; top = stk0; mode = kModeTrav;
                         }
                     }
                 }
@@ -340,7 +369,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
             for (;;) {
                 for (;;) {
-                    const int nAtNode = __popcll(ballot2_(mode == kModeTrav, (int)cur >= 0));
+                    // (cur is an internal node only while the lane traverses: every exit from kModeTrav sets cur = kNone)
+                    const int nAtNode = __popcll(ballot_((int)cur >= 0));
                     if (nAtNode == 0) break;
                     if (nAtNode < A.node_min && ballot2_(mode == kModeTrav, (int)cur < 0) != 0) break;   // few descenders: serve the leaves first
 #ifdef RT_DIAG_IDLE      // diagnostic build only: what the lanes that sit out a node step are waiting for (counters 3 / 4 re-used)
@@ -350,25 +380,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         if (lane == 0) { cnt.phase_execs[3]++; cnt.phase_execs[4]++; }
                     }
 #endif
-                    if (mode == kModeTrav && (int)cur >= 0) {
+                    if ((int)cur >= 0) {
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
                         node_step<H>(H ? S.nodes_h : S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
-                        if (gstk == nullptr || ballot_(sp + 3 > cap) == 0) {
+                        if (gstk == nullptr || ballot_(top - stk0 + 768u > capb) == 0) {
                             // branch-free push of the three farther children (far -> near); slots past the new top are garbage
-                            stk[sp * 64] = c3; sp += (t3 < INF) ? 1 : 0;
-                            stk[sp * 64] = c2; sp += (t2 < INF) ? 1 : 0;
-                            stk[sp * 64] = c1; sp += (t1 < INF) ? 1 : 0;
+                            slot(top) = c3; top = (t3 < INF) ? top + 256u : top;
+                            slot(top) = c2; top = (t2 < INF) ? top + 256u : top;
+                            slot(top) = c1; top = (t1 < INF) ? top + 256u : top;
                         } else {
                             // some lane is within three entries of the LDS part: checked pushes, spilling past it
-                            if (t3 < INF) { if (sp < cap) stk[sp * 64] = c3; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c3; ++sp; }
-                            if (t2 < INF) { if (sp < cap) stk[sp * 64] = c2; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c2; ++sp; }
-                            if (t1 < INF) { if (sp < cap) stk[sp * 64] = c1; else gstk[(size_t)(sp - cap) * F.gstack_stride] = c1; ++sp; }
+                            auto push = [&](uint32_t c) {
+                                const uint32_t depth = top - stk0;
+                                if (depth < capb) slot(top) = c; else gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride] = c;
+                                top += 256u;
+                            };
+                            if (t3 < INF) push(c3);
+                            if (t2 < INF) push(c2);
+                            if (t1 < INF) push(c1);
                         }
                         if (t0 < INF) cur = c0;
-                        else if (sp > 0) cur = pop();
+                        else if (top != stk0) cur = pop();
                         else { cur = kNone; mode = kModeShade; }
                     }
                 }
@@ -392,7 +427,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                                 uint32_t ob = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3 + 1].w);
                                 take = oc < ob;
                             }
-                            if (take && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
+                            if (take && F.p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
                                 // the reference only reaches this triangle if its chunk's box test passes (:279)
                                 uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
                                 float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                         }
                     }
-                    if (sp > 0) cur = pop();
+                    if (top != stk0) cur = pop();
                     else { cur = kNone; mode = kModeShade; }
                 }
                 if (ballot_(mode == kModeTrav) == 0) break;
