@@ -433,6 +433,23 @@ __device__ __forceinline__ float mod2(float x) { return x - 2.0f * __builtin_flo
 
 struct Camera { v3 focusPoint, right, up, pos; float W; };
 
+// A *fresh* view of a kernel's argument segment (KA = the kernel's parameters as one struct, in order).  The megakernels are
+// persistent loops with regions that need different arguments (traversal: node / triangle arrays; shading: materials, camera,
+// environment; scheduling: queue and tile tables).  Read through the kernel's own parameters they are all loop invariants: the
+// compiler keeps every one of them in SGPRs across the whole loop, runs out (k_stream: 86 SGPRs spilled to VGPR lanes) and pays
+// a VALU v_readlane_b32 per use — on the port that bounds the kernel.  A region that starts with fresh_kernargs() re-reads what it
+// needs from the kernarg segment with scalar loads instead (the pointer goes through an empty asm, so nothing read through it can
+// be hoisted out of the region) and the values die with the region.
+template <class KA>
+__device__ __forceinline__ const KA& fresh_kernargs()
+{
+    auto kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const KA*)(const char*)kp;
+}
+static_assert(alignof(DeviceScene) <= 8 && alignof(FrameArgs) <= 8, "kernarg layout = struct layout");
+// (k_trace's loop body is one shading-dominated region: the same treatment measured -0.8 % on the sphere workload and is not applied.)
+
 // frag :377-382 — one camera ray (4 RNG draws)
 template <class R>
 __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, R& rng, v3& o, v3& d)

@@ -41,20 +41,8 @@ struct StreamArgs {
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
 
-// The kernel's argument segment as one struct, and a *fresh* view of it.  The persistent loop below has three regions (work-item
-// fetch, SHADE, traversal burst) that need different arguments; read through the kernel's own parameters they are all loop
-// invariants, the compiler keeps every one of them in SGPRs across the whole loop, runs out (86 SGPRs spilled to VGPR lanes) and
-// pays a VALU v_readlane_b32 for each use — on the kernel's binding port.  A region that starts with fresh_args() re-reads what it
-// needs from the kernarg segment with scalar loads instead (the pointer goes through an empty asm, so nothing read through it can
-// be hoisted out of the region), and the values die with the region.
-struct StreamKernArgs { DeviceScene S; FrameArgs F; StreamArgs A; };
-static_assert(alignof(DeviceScene) <= 8 && alignof(FrameArgs) <= 8 && alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
-__device__ __forceinline__ const StreamKernArgs& fresh_args()
-{
-    auto kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    return *(const StreamKernArgs*)(const char*)kp;
-}
+struct StreamKernArgs { DeviceScene S; FrameArgs F; StreamArgs A; };     // k_stream's argument segment (fresh_kernargs, rt_kernels.hpp)
+static_assert(alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
 
 template <bool COUNT, bool PHILOX = false, bool H = false>
 // Five waves per SIMD (96 VGPRs, 15 dwords of scratch in the SHADE phase, LDS stack of <= 31 entries per lane so that five workgroups
@@ -157,7 +145,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
-            const StreamKernArgs& KA = fresh_args();
+            const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
             const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
             const unsigned int nitems_ = (unsigned)A.n1 * ntiles_ + (unsigned)A.n4 * (ntiles_ << 2) + (unsigned)A.n16 * (ntiles_ << 4);
@@ -198,7 +186,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             // shading waves fill the gaps: +4.5 % / +3.3 % on the two triangle workloads (0/0: 12.86, trav 1 / shade 0: 13.44,
             // trav 0 / shade 1: 12.91, node loop 2 / leaves 1 / shade 0: 13.44 Grays/s).
             __builtin_amdgcn_s_setprio(0);
-            const StreamKernArgs& KA = fresh_args();
+            const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const DeviceScene& S = KA.S; const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
             const rt_params& p = F.p;
             const float* M = p.camLocalToWorld;
