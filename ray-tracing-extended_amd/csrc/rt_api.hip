@@ -158,6 +158,21 @@ void pack_material(const rt_material& m, float4* out)
     out[3] = make_float4(m.emissionStrength, m.smoothness, m.specularProbability, u2f((uint32_t)m.flag));
 }
 
+// True when every camera ray starts exactly at worldSpaceCameraPos (frag :377-378 with defocusStrength = +-0): the jitter is
+// (finite * +-0) / width = +-0, the basis vectors times it are +-0 when they are finite, and pos + (+-0) = pos bit for bit unless a
+// component of pos is -0 (which a +0 turns into +0) or not finite.  The kernels then skip that arithmetic (camera_ray).
+bool camera_origin_is_fixed(const rt_params& p)
+{
+    if (!(p.defocusStrength == 0.0f) || p.width < 1) return false;
+    const int basis[6] = { 0, 4, 8, 1, 5, 9 };                   // camera right and up (columns 0 and 1 of camLocalToWorld)
+    for (int k : basis) if (!std::isfinite(p.camLocalToWorld[k])) return false;
+    for (int a = 0; a < 3; ++a) {
+        const float v = p.worldSpaceCameraPos[a];
+        if (!std::isfinite(v) || (v == 0.0f && std::signbit(v))) return false;
+    }
+    return true;
+}
+
 // Largest |coordinate| a camera-ray origin can have: camera position plus the defocus disc (frag :377-378).
 float camera_magnitude(const rt_params& p)
 {
@@ -561,6 +576,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const bool stream_spill = stream && F.stack_cap > c->opt_stream_stack;
     if (stream_spill) F.stack_cap = c->opt_stream_stack;
     F.full_sort = c->opt_full_sort;
+    F.fixed_origin = camera_origin_is_fixed(c->params) ? 1 : 0;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
     F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
 

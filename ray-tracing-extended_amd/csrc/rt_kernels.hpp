@@ -53,6 +53,8 @@ struct FrameArgs {
     int tile_w_log2;            // k_trace: a wave's tile is 2^tile_w_log2 pixels wide and 64 >> tile_w_log2 rows tall (3: 8x8)
     int stack_cap;              // LDS stack entries per lane
     int full_sort;              // 1: sort all four children of a node by distance, 0: nearest first only
+    int fixed_origin;           // 1: every camera ray starts exactly at worldSpaceCameraPos (defocusStrength is +-0 and the camera basis is
+                                //    finite): camera_ray skips the arithmetic of the defocus jitter, whose result is pos + (+-0) = pos
     uint32_t* gstack;           // overflow of the traversal stack beyond stack_cap ([entry][lane of the launch]); may be null
     unsigned int gstack_stride; // lanes of the launch
     float4* out_frame;          // [nrows*W] currentFrame
@@ -451,13 +453,21 @@ static_assert(alignof(DeviceScene) <= 8 && alignof(FrameArgs) <= 8, "kernarg lay
 // (k_trace's loop body is one shading-dominated region: the same treatment measured -0.8 % on the sphere workload and is not applied.)
 
 // frag :377-382 — one camera ray (4 RNG draws)
+// fixed_origin (wave-uniform, decided by the host: FrameArgs::fixed_origin): defocusStrength is +-0, so the jitter is
+// (finite * +-0) / W = +-0, right * +-0 and up * +-0 are +-0 (finite basis) and pos + (+-0) = pos bit for bit (pos finite and no
+// component -0, the one value a +0 would change).  The two draws of the jitter are still taken from the stream.
 template <class R>
-__device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, R& rng, v3& o, v3& d)
+__device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, R& rng, v3& o, v3& d, bool fixed_origin = false)
 {
     float jx, jy;
-    rtm::random_point_in_circle(rng, jx, jy);
-    jx = jx * p.defocusStrength / c.W; jy = jy * p.defocusStrength / c.W;
-    o = (c.pos + c.right * jx) + c.up * jy;
+    if (fixed_origin) {
+        (void)rtm::random_value(rng); (void)rtm::random_value(rng);
+        o = c.pos;
+    } else {
+        rtm::random_point_in_circle(rng, jx, jy);
+        jx = jx * p.defocusStrength / c.W; jy = jy * p.defocusStrength / c.W;
+        o = (c.pos + c.right * jx) + c.up * jy;
+    }
     rtm::random_point_in_circle(rng, jx, jy);
     jx = jx * p.divergeStrength / c.W; jy = jy * p.divergeStrength / c.W;
     v3 jfp = (c.focusPoint + c.right * jx) + c.up * jy;
@@ -466,7 +476,7 @@ __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, 
 
 // One pixel of one frame: frag :356-389 as a flat state machine (see file header).
 template <bool COUNT, bool FLAT, bool PHILOX, bool H = false>
-__device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, int frame, int x, int y,
+__device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, bool fixed_origin, int frame, int x, int y,
                                            const TravStack& stk, Counters& cnt)
 {
     const float* M = p.camLocalToWorld;
@@ -492,7 +502,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
     v3 rayColour = rtm::mk(1.f, 1.f, 1.f), light = rtm::mk(0.f, 0.f, 0.f);
     int sample = 0, bounce = 0;
     bool alive = p.numRaysPerPixel > 0;
-    if (alive) camera_ray(p, cam, rng, o, d);
+    if (alive) camera_ray(p, cam, rng, o, d, fixed_origin);
 
     while (alive) {
         Hit h; v3 nrm_flat; uint32_t chunk_flat;
@@ -565,7 +575,7 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
             if (sample >= p.numRaysPerPixel) alive = false;
             else {
                 phase_tick<COUNT>(cnt, 4);
-                camera_ray(p, cam, rng, o, d);
+                camera_ray(p, cam, rng, o, d, fixed_origin);
                 bounce = 0;
                 rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
             }
@@ -613,7 +623,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
         const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
-            v3 c = render_pixel<COUNT, FLAT, PHILOX, H>(S, F.p, F.full_sort != 0, F.frame + (int)fi, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT, PHILOX, H>(S, F.p, F.full_sort != 0, F.fixed_origin != 0, F.frame + (int)fi, x, y, stk, cnt);
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[(size_t)fi * F.frame_stride + pi] = make_float4(c.x, c.y, c.z, 1.0f);     // frag :388
             if (!batched) {

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,
                                                  ((M[4] * lx + M[5] * lyv) + M[6]  * lz) + M[7]  * 1.0f,
                                                  ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f);
-                        camera_ray(p, cam, rng, o, d);
+                        camera_ray(p, cam, rng, o, d, F.fixed_origin != 0);
                         bounce = 0;
                         rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
                     }

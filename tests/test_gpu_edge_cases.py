@@ -79,6 +79,30 @@ def test_axis_aligned_rays_zero_direction_components(rtx, oracle, tracer):
         check(rtx, oracle, tracer, mm, frames=1, what=f"axis-aligned mode {mode}")
 
 
+def test_fixed_camera_origin_shortcut_and_the_cases_it_must_not_take(rtx, oracle, tracer):
+    """defocusStrength = +-0 lets camera_ray take the camera position as the ray origin without the jitter arithmetic
+    (pos + (+-0) = pos; rt_api.hip camera_origin_is_fixed).  A camera coordinate of -0 is the one value that arithmetic
+    changes (-0 + +0 = +0), so such a camera has to stay on the general path; a tiny non-zero defocus as well."""
+    m = rtx.scenes.mesh_test_scene(48, 30)
+    m.numRaysPerPixel, m.maxBounceCount = 3, 3
+    cases = {"+0 defocus": (0.0, None), "-0 defocus": (-0.0, None), "camera x = -0": (0.0, 0), "camera z = -0": (-0.0, 2),
+             "denormal defocus": (1e-42, None)}
+    for what, (defocus, neg_zero_axis) in cases.items():
+        m.defocusStrength = defocus
+        params, spheres, tris, infos = m.build_buffers()
+        params = params.copy()
+        params["defocusStrength"] = np.float32(defocus)
+        if neg_zero_axis is not None:
+            params["worldSpaceCameraPos"][neg_zero_axis] = np.float32(-0.0)
+            params["camLocalToWorld"][4 * neg_zero_axis + 3] = np.float32(-0.0)
+        b = (params, spheres, tris, infos)
+        want, want_last, _ = oracle.render(*b, 0, 2)
+        for k in (0, 1):
+            acc, last = run_gpu(tracer, b, 0, 2, kernel=k)
+            assert_bitwise(last, want_last, f"{what} kernel {k} last frame")
+            assert_bitwise(acc, want, f"{what} kernel {k} accum")
+
+
 def test_depth_of_field_and_invisible_light(rtx, oracle, tracer):
     """Chess.unity settings (defocus 180, diverge 1, focus 3.82) on the reference scene: exercises the defocus jitter
     (frag :377-378) and the InvisibleLightSource flag at bounce 0 (Trace :318-322)."""
