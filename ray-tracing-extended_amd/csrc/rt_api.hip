@@ -17,6 +17,7 @@
 
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
+namespace rtk { const void* stream_kernel(bool counting, bool philox, bool compact); }   // rt_stream_kernels.hip
 #include "rt_pool.hpp"
 #include "rt_wave.hpp"
 #include "rt_geom.hpp"
@@ -591,7 +592,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
                    : pooled ? (counting ? (const void*)rtk::k_pool<true> : (const void*)rtk::k_pool<false>)
                    : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
-                   : stream ? dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_stream<decltype(C)::value, decltype(P)::value, decltype(H)::value>; })
+                   : stream ? rtk::stream_kernel(counting, philox, compact)       // instantiated in rt_stream_kernels.hip
                    : c->n_nodes == 0      // spheres only: the instantiation compiled for six waves per SIMD
                             ? dispatch3(counting, philox, false, [](auto C, auto P, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, false, 6>; })
                             : dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, decltype(H)::value>; });
@@ -700,7 +701,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         RT_HIP(c, hipGetLastError());
         if (nb > 1) {
             const int ag = (int)std::min<size_t>((c->target_pixels + 255) / 256, (size_t)c->n_cu * 8);
-            hipLaunchKernelGGL(rtk::k_accumulate, dim3(ag), dim3(256), 0, c->stream, c->d_batch.p, c->d_accum.p, c->d_frame.p,
+            hipLaunchKernelGGL(rtk::k_accumulate<>, dim3(ag), dim3(256), 0, c->stream, c->d_batch.p, c->d_accum.p, c->d_frame.p,
                                c->target_pixels, F.frame_stride, F.frame, nb);
             RT_HIP(c, hipGetLastError());
         }

@@ -651,6 +651,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
 }
 
 // Accumulate.shader:43-54 for a batch of frames traced by one launch: per pixel, frames first .. first+n-1 in order.
+// (a template only so that this header can be included by more than one translation unit)
+template <int = 0>
 __global__ __launch_bounds__(256) void k_accumulate(const float4* __restrict__ frames, float4* __restrict__ accum,
                                                     float4* __restrict__ last_frame, size_t pixels, unsigned int frame_stride,
                                                     int first_frame, int n_frames)
