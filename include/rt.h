@@ -203,7 +203,8 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "node_min"        k_stream: inside a burst the node loop goes on while at least this many lanes hold an internal node (or no
  *                     lane holds a leaf); below it the leaves are served first (default 10; 1 = classic while-while)
  *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch while the launch's queue is long; a lane that finishes its pixel of
- *                     one item moves on to its position in the next instead of idling until the item's slowest pixel is done (default 12)
+ *                     one item moves on to its position in the next instead of idling until the item's slowest pixel is done (default 16 = the 16
+ *                     sub-tiles of one 8x8 tile when 16 frames are interleaved)
  *   "fetch_guide"     k_stream: guided self-scheduling — groups of tiles_per_fetch items while more than fetch_guide groups per wave of
  *                     the launch are left in the queue, then items_left / (waves x fetch_guide), down to single items (default 4)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel

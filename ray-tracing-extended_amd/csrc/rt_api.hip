@@ -108,8 +108,9 @@ struct rt_ctx {
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
     int opt_fetch_guide = 4;        // k_stream: groups of tiles_per_fetch items while more than this many groups per wave are left (then smaller)
-    int opt_tiles_per_fetch = 12;   // k_stream: items a wave reserves per fetch while the queue is long (guided: fewer near the end).  Fixed groups of
-                                    // 2 / 4 / 8: 11.89 / 12.17 / 11.65 Grays/s (the tail grows); guided 4 / 8 / 12 / 16 / 24: 12.35 / 12.55 / 12.60 / 12.61 / 12.60
+    int opt_tiles_per_fetch = 16;   // k_stream: items a wave reserves per fetch while the queue is long (guided: fewer near the end).  Fixed groups of
+                                    // 2 / 4 / 8: 11.89 / 12.17 / 11.65 Grays/s (the tail grows); guided 4 / 8 / 12 / 16 / 24: 12.35 / 12.55 / 12.60 / 12.61 / 12.60.
+                                    // 16 = the sub-tiles of one 8x8 tile in a 2x2x16 launch: groups stay tile-aligned (15.31 against 15.26 at 12)
     int opt_compact_nodes = 1;      // k_trace / k_stream: traverse the f16 form of the nodes (Node4h: 5 loads per visit instead of 7)
     int opt_stream_tile = 4;        // k_stream: log2 of the most frames interleaved in a wave (0: 8x8 pixels x 1 frame, 2: 4x4 x 4, 4: 2x2 x 16)
                                     // measured on the 100k-triangle workload: 10.86 / 11.48 / 11.89 Grays/s; with 4 tiles per fetch 12.17

@@ -314,7 +314,7 @@ def test_tile_groups_multi_frame(rtx, oracle, tracer, size, k):
         acc, last = run_gpu(tracer, b, 1, 3, kernel=1)
         st = tracer.stats()
     finally:
-        tracer.set_option("tiles_per_fetch", 12)
+        tracer.set_option("tiles_per_fetch", 16)
     want, want_last, cnt = oracle.render(*b, 1, 3)
     assert_bitwise(last, want_last, f"{size} k={k}: last frame")
     assert_bitwise(acc, want, f"{size} k={k}: accum")
