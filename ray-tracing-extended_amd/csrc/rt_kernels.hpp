@@ -450,7 +450,8 @@ __device__ __forceinline__ const KA& fresh_kernargs()
     return *(const KA*)(const char*)kp;
 }
 static_assert(alignof(DeviceScene) <= 8 && alignof(FrameArgs) <= 8, "kernarg layout = struct layout");
-// (k_trace's loop body is one shading-dominated region: the same treatment measured -0.8 % on the sphere workload and is not applied.)
+struct TraceKernArgs { DeviceScene S; FrameArgs F; };                     // k_trace(DeviceScene, FrameArgs)
+// (k_trace's pixel loop is one shading-dominated region: the same treatment measured -0.8 % on the sphere workload and is not applied.)
 
 // frag :377-382 — one camera ray (4 RNG draws)
 // fixed_origin (wave-uniform, decided by the host: FrameArgs::fixed_origin): defocusStrength is +-0, so the jitter is
@@ -606,8 +607,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
     const unsigned int nitems = (unsigned)ntiles * (unsigned)(batched ? F.frames_in_launch : 1);
     const float weight = 1.0f / (float)(F.frame + 1);                                  // Accumulate.shader:48
     const float omw = 1.0f - weight;
+    const rt_params& P = F.p;
+    const bool full_sort = F.full_sort != 0, fixed_origin = F.fixed_origin != 0;
 
     for (;;) {
+        // (what a tile needs before and after its pixels is read fresh — fresh_kernargs — so that it does not sit in SGPRs during
+        // the pixel loop; the pixel loop itself keeps the kernel's plain parameters, see there)
+        const TraceKernArgs& KA = fresh_kernargs<TraceKernArgs>();
+        const FrameArgs& F = KA.F;
         // work item = (frame, tile), frame-major: with several frames per launch the wave count no longer has to be
         // matched by the tile count for the persistent waves to balance (frames are independent: frag :362 seeds by Frame)
         unsigned int item = 0;
@@ -623,7 +630,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
         const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
-            v3 c = render_pixel<COUNT, FLAT, PHILOX, H>(S, F.p, F.full_sort != 0, F.fixed_origin != 0, F.frame + (int)fi, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT, PHILOX, H>(S, P, full_sort, fixed_origin, F.frame + (int)fi, x, y, stk, cnt);
+            const TraceKernArgs& KB = fresh_kernargs<TraceKernArgs>();
+            const FrameArgs& F = KB.F;
             const size_t pi = (size_t)ly * F.p.width + x;
             F.out_frame[(size_t)fi * F.frame_stride + pi] = make_float4(c.x, c.y, c.z, 1.0f);     // frag :388
             if (!batched) {
