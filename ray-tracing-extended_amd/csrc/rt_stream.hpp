@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                     else { cur = kNone; mode = kModeShade; }
                 }
                 if (ballot_(mode == kModeTrav) == 0) break;
-                if (__popcll(ballot_(mode == kModeShade)) >= thr) break;
+                if ((int)__popcll(ballot_(mode == kModeShade)) >= thr) break;
             }
         }
     }
