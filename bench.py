@@ -252,9 +252,20 @@ def main():
         tf = os.path.join(ROOT, "profiles", "pmc_table.json")
         if os.path.exists(tf) and world == 1 and args.rng == "pcg":
             try:
-                ent = json.load(open(tf)).get(f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}")
+                table = json.load(open(tf))
             except Exception:
-                ent = None
+                table = {}
+            exact = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}"
+            ent = table.get(exact) if nrows == H else None
+            if ent is None:
+                # the same scene at another resolution / ray count, or a part of the image (--as-rank-of): the per-frame figures of
+                # its committed pass, scaled by rays (the instruction and byte counts per ray of a scene do not depend on the image size)
+                for key, cand in sorted(table.items(), key=lambda kv: kv[0] != exact):
+                    if key.startswith(f"config{args.config}_") and cand.get("rays_per_frame") and sc["rays"] and args.steps:
+                        k = (sc["rays"] / args.steps) / cand["rays_per_frame"]
+                        ent = {f: (v * k if f.endswith("_per_frame") and isinstance(v, (int, float)) else v) for f, v in cand.items()}
+                        ent["source"] = f"{cand.get('source')}; scaled by rays per frame x{k:.4f} from {key}"
+                        break
             if ent and ent.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
                 pmc = ent
                 traffic = int(ent["hbm_bytes_per_frame"] * fpl)

@@ -29,6 +29,11 @@ ent = {
     "wait_inst_any_frac_of_wave_cycles": d.get("SQ_WAIT_INST_ANY_frac_of_wave_cycles"),
     "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc, one counter group per pass; mean over the {fpl}-frame launches of each pass)",
 }
+# rays per frame of this workload (from its committed bench line): lets bench.py scale the entry to another resolution of the same scene
+bj = os.path.join(root, "profiles", f"bench_r02_config{config}.json")
+if os.path.exists(bj):
+    bd = json.loads(open(bj).read().strip().splitlines()[-1])
+    ent["rays_per_frame"] = round(bd["value"] * 1e6 * bd["ms_per_step"] * 1e-3)
 path = os.path.join(root, "profiles", "pmc_table.json")
 table = json.load(open(path)) if os.path.exists(path) else {}
 table[f"config{config}_{W}x{H}_{rays}"] = ent
