@@ -250,7 +250,7 @@ def main():
         # any --steps scales them; only for the N = 1 launch they were measured on
         pmc, traffic = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_table.json")
-        if os.path.exists(tf) and world == 1 and args.rng == "pcg":
+        if os.path.exists(tf) and world == 1:
             try:
                 table = json.load(open(tf))
             except Exception:
@@ -268,6 +268,8 @@ def main():
                         break
             if ent and ent.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
                 pmc = ent
+                if args.rng != "pcg":       # the committed passes ran the reference's PCG stream; Philox issues more instructions per draw
+                    pmc = dict(ent, source=f"{ent.get('source')}; pass of the PCG stream: a lower bound for the Philox mode")
                 traffic = int(ent["hbm_bytes_per_frame"] * fpl)
         hbm = {"peak": PEAK_HBM_GBPS, "unit": "GB/s",
                "algorithmic_survey_32B_nodes": round(alg_bytes(NODE_BYTES_SURVEY) / launch_s / 1e9, 1),
