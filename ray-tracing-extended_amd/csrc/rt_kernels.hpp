@@ -308,12 +308,24 @@ __device__ __forceinline__ Hit closest_hit(const DeviceScene& S, int intersect_m
     // CalculateRayCollision :263-273 — buffer order, strict '<' (first sphere wins ties)
     const float a = rtm::dot(d, d);
     const SphereA sa = sphere_a(a);
-    for (int i = 0; i < S.ns; ++i) {
-        float4 s = S.sph_geom[i];
+    // (four, then two sphere records per trip: the compiler waits for every load right where it issues it, so a sphere test otherwise
+    // pays the full latency of its own 16 bytes.  Sphere workload: 40.23 one by one, 41.28 by two, 41.59 Grays/s by four)
+    auto test = [&](const float4 s, int i) {
         float dst;
         if (COUNT) cnt.sph++;
         if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+    };
+    int i = 0;
+    for (; i + 3 < S.ns; i += 4) {
+        const float4 s0 = S.sph_geom[i], s1 = S.sph_geom[i + 1], s2 = S.sph_geom[i + 2], s3 = S.sph_geom[i + 3];
+        test(s0, i); test(s1, i + 1); test(s2, i + 2); test(s3, i + 3);
     }
+    for (; i + 1 < S.ns; i += 2) {
+        const float4 s0 = S.sph_geom[i], s1 = S.sph_geom[i + 1];
+        test(s0, i);
+        test(s1, i + 1);
+    }
+    for (; i < S.ns; ++i) test(S.sph_geom[i], i);
 
     if (S.nn > 0 && ray_traceable(o, d, a)) {
         const RaySlabT<H> slab = make_slab<H>(o, d);
