@@ -50,6 +50,23 @@ def kernel_metadata(elf):
     return []
 
 
+def test_k_trace_kernarg_segment_is_laid_out_like_the_struct_view():
+    """k_trace reads the per-tile part of its arguments through TraceKernArgs = {DeviceScene, FrameArgs}"""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    blob = open(LIB, "rb").read()
+    seen = 0
+    for elf in code_objects(blob):
+        for k in kernel_metadata(elf):
+            if "k_trace" not in k[".name"]:
+                continue
+            args = [a for a in k[".args"] if a[".value_kind"] == "by_value"]
+            assert len(args) == 2, k[".name"]
+            assert args[0][".offset"] == 0 and args[1][".offset"] == (args[0][".size"] + 7) & ~7, (k[".name"], args)
+            seen += 1
+    assert seen >= 8
+
+
 def test_k_stream_kernarg_segment_is_laid_out_like_the_struct_view():
     if not os.path.exists(LIB):
         pytest.skip("library not built")
