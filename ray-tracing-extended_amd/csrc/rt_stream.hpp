@@ -45,9 +45,10 @@ struct StreamKernArgs { DeviceScene S; FrameArgs F; StreamArgs A; };     // k_st
 static_assert(alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
 
 template <bool COUNT, bool PHILOX = false, bool H = false>
-// Five waves per SIMD (96 VGPRs, 15 dwords of scratch in the SHADE phase, LDS stack of <= 31 entries per lane so that five workgroups
-// fit a CU): the kernel hides its memory and LDS latencies with resident waves — 3 / 4 / 5 / 6 waves per SIMD give 10.4 / 12.4 / 12.9 /
-// 11.2 Grays/s on the 100k-triangle workload (6 waves = 80 VGPRs spill 31 dwords), 11.85 -> 12.75 on the million-triangle one.
+// Five waves per SIMD (96 VGPRs: 95 used, no scratch; LDS stack of <= 31 entries per lane so that five workgroups fit a CU): the
+// kernel hides its memory and LDS latencies with resident waves — 3 / 4 / 5 / 6 waves per SIMD gave 10.4 / 12.4 / 12.9 / 11.2 Grays/s
+// on the 100k-triangle workload when this was chosen (11.85 -> 12.75 on the million-triangle one); on the final, spill-free kernel
+// six waves (80 VGPRs, 26 dwords of scratch) measure 14.18 against 14.70 at five.
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES 5
 #endif
