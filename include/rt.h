@@ -83,8 +83,24 @@ typedef struct rt_local_chunk {         /* 80 B: one MeshChunk of RayTracedMesh.
 
 enum {
     RT_RNG_PCG = 0,                     /* RayTracing.shader:193-204 — the reference's stream, the parity mode            */
-    RT_RNG_PHILOX = 1                   /* counter-based Philox4x32-10, key (pixelIndex, Frame), draw i = word i&3 of
-                                           block i>>2; NOT the reference's stream (different noise, same estimator)     */
+    RT_RNG_PHILOX = 1                   /* the perf mode: counter-based Philox4x32-10 (Salmon et al., SC'11).  NOT the reference's
+                                           stream: different noise, same expectation.  The reference chains one PCG state through every
+                                           sample and bounce of a pixel (RayTracing.shader:362,374-385), which forbids spreading a
+                                           pixel's samples over lanes; here every draw is addressed by what it is for:
+                                             key     = (pixelIndex, Frame)                     (frag :360-362)
+                                             counter = (block, sample, 0, 0)
+                                             block 0               the sample's camera ray: words 0..3 = the four draws of frag
+                                                                   :377,380 in the shader's order
+                                             blocks 1+2b, 2+2b     the hit at loop index b of Trace (:305): the eight draws of
+                                                                   :325-339 in the shader's order, words 0..3 of the first block,
+                                                                   then of the second (a bounce that draws nothing leaves them unused)
+                                           and the estimator's sum over the NumRaysPerPixel samples (:384) is a fixed tree instead of a
+                                           left-to-right chain: sample s goes to sub-stream s mod S, S = 16 / 4 / 1 for NumRaysPerPixel
+                                           >= 16 / >= 4 / else; a sub-stream adds its samples in increasing order starting from 0;
+                                           the S sub-sums are added pairwise, (k, k+1) for even k, then (k, k+2) for k = 0 mod 4, ...;
+                                           the root is divided by NumRaysPerPixel (:387).  Scatter, Russian roulette and everything
+                                           else are the reference's.  On the device the S sub-streams of a pixel are S lanes of one
+                                           wave (k_stream's Philox instantiation), the tree is an in-wave reduction                  */
 };
 enum {
     RT_INTERSECT_FLAT_CHUNKS = 0,       /* literal reference result: a triangle counts only if its chunk's
@@ -144,6 +160,9 @@ typedef struct rt_stats {
     int32_t  bvhBuiltOnDevice;          /* 1: the current tree came from the device builder                              */
     int32_t  bvhBuilds;                 /* builds since rt_create                                                        */
     int32_t  bvhRebuilds;               /* ... of which triggered by a refit that had inflated the tree                  */
+    int32_t  bvhRepads;                 /* times the box padding was widened on the device (a ray origin moved beyond the magnitude the
+                                           boxes were padded for: refit of the existing tree, no rebuild, no re-upload)   */
+    int32_t  lastSampleLanes;           /* Philox mode: lanes of a wave that shared a pixel's samples in the last launch (16, 4 or 1) */
     int32_t  _reserved;
 } rt_stats;
 
@@ -193,7 +212,7 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "bvh_bins", "bvh_cost_exp", "bvh_reinsert"   BVH builder: SAH bins per axis (32); exponent, in percent, of the triangle
  *                     count in the SAH's subtree-cost model (100); passes of insertion-based optimisation of the binary tree (0:
  *                     measured -3 % node visits per ray but no fewer wave-level steps)
- *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (31 = five workgroups per CU); a BVH whose worst
+ *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (30 = five workgroups per CU); a BVH whose worst
  *                     case is deeper spills the rest to global memory
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order

@@ -195,8 +195,20 @@ float orc_random_value(uint32_t* state)
     return (float)orc_next_random(state) * 2.3283064365386963e-10f;           /* r / 2^32 (shader :203) */
 }
 /* Counter-based alternative (rngMode = RT_RNG_PHILOX; not a reference mode — the north-star's perf mode): Philox4x32-10
- * (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11).  Draw number i of a pixel in a frame, in the order
- * the shader draws, is word i&3 of philox(counter = (i>>2, 0, 0, 0), key = (pixelIndex, Frame)). */
+ * (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), key = (pixelIndex, Frame), counter = (block, sample, 0, 0).
+ * The reference chains one PCG state through every sample and bounce of a pixel (RayTracing.shader:362,374-385), which forbids
+ * spreading a pixel's samples over lanes; here every draw is addressed by what it is for, so samples (and bounces) are independent:
+ *   block 0                 the sample's camera ray: words 0..3 = the four draws of frag :377,380 in the shader's order
+ *                           (defocus angle, defocus radius, diverge angle, diverge radius)
+ *   blocks 1 + 2b, 2 + 2b   the hit at loop index `bounce` = b of Trace (:305): the eight draws of :325-339 in the shader's order
+ *                           (isSpecular; theta, rho of the x, y, z normal deviates; Russian roulette) = words 0..3 of the first block,
+ *                           then words 0..3 of the second.  A bounce that draws nothing (InvisibleLightSource :318-322, a miss) leaves
+ *                           its blocks unused.
+ * The estimator's sum over the NumRaysPerPixel samples (:384) is a fixed tree instead of a left-to-right chain, so that a wavefront can
+ * evaluate it in parallel: sample s goes to sub-stream s mod S, S = orc_philox_substreams(NumRaysPerPixel) = 16 / 4 / 1; a sub-stream
+ * adds its samples in increasing order, starting from 0; the S sub-sums are combined pairwise — (k, k + 1) for even k, then (k, k + 2)
+ * for k = 0 mod 4, ... — and the root is divided by NumRaysPerPixel (:387).  Scatter, Russian roulette and everything else are the
+ * reference's.  Different noise than the PCG mode, same expectation. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
@@ -209,17 +221,22 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-typedef struct { int mode; uint32_t state, key[2], cache[4]; } orng;     /* state: PCG state, or the Philox draw counter */
+typedef struct { int mode; uint32_t state /* PCG */, key[2], sample, block, n, cache[4]; } orng;
+
+int orc_philox_substreams(int rays_per_pixel) { return rays_per_pixel >= 16 ? 16 : rays_per_pixel >= 4 ? 4 : 1; }
+
+/* Philox mode: the draws that follow are words 0, 1, 2, ... of blocks `block`, `block` + 1, ... of the current sample */
+static inline void rng_scope(orng* g, uint32_t block) { g->block = block; g->n = 0; }
 
 static float rnd(orng* g)
 {
     if (g->mode == RT_RNG_PCG) return orc_random_value(&g->state);
-    if ((g->state & 3u) == 0u) {
-        uint32_t ctr[4] = { g->state >> 2, 0u, 0u, 0u };
+    if ((g->n & 3u) == 0u) {
+        uint32_t ctr[4] = { g->block + (g->n >> 2), g->sample, 0u, 0u };
         orc_philox4x32_10(ctr, g->key, g->cache);
     }
-    uint32_t r = g->cache[g->state & 3u];
-    g->state++;
+    uint32_t r = g->cache[g->n & 3u];
+    g->n++;
     return (float)r * 2.3283064365386963e-10f;
 }
 
@@ -544,6 +561,7 @@ static v3 trace(const scene_t* sc, v3 o, v3 d, orng* rng, orc_counts* cnt)
                 o = v_add(h.hitPoint, v_scale(d, 0.001f));
                 continue;
             }
+            rng_scope(rng, 1u + 2u * (uint32_t)bounce);
             int isSpecular = m->specularProbability >= rnd(rng);  /* :325 */
             float specF = isSpecular ? 1.0f : 0.0f;
             o = h.hitPoint;                                                    /* :327 */
@@ -576,7 +594,7 @@ static void frag(const scene_t* sc, int x, int y, int frame, float* out, orc_cou
     float Wf = (float)W, Hf = (float)H;
     float uvx = ((float)x + 0.5f) / Wf, uvy = ((float)y + 0.5f) / Hf;
     uint32_t pixelIndex = (uint32_t)y * W + (uint32_t)x;
-    orng rng;
+    orng rng; memset(&rng, 0, sizeof rng);
     rng.mode = p->rngMode;
     rng.state = (p->rngMode == RT_RNG_PCG) ? pixelIndex + (uint32_t)frame * 719393u : 0u;      /* :362 */
     rng.key[0] = pixelIndex; rng.key[1] = (uint32_t)frame;
@@ -592,8 +610,12 @@ static void frag(const scene_t* sc, int x, int y, int frame, float* out, orc_cou
     v3 camPos   = v_load(p->worldSpaceCameraPos);
 
     v3 total = V(0, 0, 0);
+    v3 part[16];                                                   /* Philox mode: the sub-streams' sums */
+    const int S = orc_philox_substreams(p->numRaysPerPixel);
+    for (int k = 0; k < 16; k++) part[k] = V(0, 0, 0);
     for (int rayIndex = 0; rayIndex < p->numRaysPerPixel; rayIndex++) {
         float jx, jy;
+        rng.sample = (uint32_t)rayIndex; rng_scope(&rng, 0u);
         random_point_in_circle(&rng, &jx, &jy);
         jx = jx * p->defocusStrength / Wf;  jy = jy * p->defocusStrength / Wf;
         v3 origin = v_add(v_add(camPos, v_scale(camRight, jx)), v_scale(camUp, jy));
@@ -602,7 +624,14 @@ static void frag(const scene_t* sc, int x, int y, int frame, float* out, orc_cou
         jx = jx * p->divergeStrength / Wf;  jy = jy * p->divergeStrength / Wf;
         v3 jfp = v_add(v_add(focusPoint, v_scale(camRight, jx)), v_scale(camUp, jy));
         v3 dir = v_normalize(v_sub(jfp, origin));
-        total = v_add(total, trace(sc, origin, dir, &rng, cnt));
+        v3 light = trace(sc, origin, dir, &rng, cnt);
+        if (p->rngMode == RT_RNG_PCG) total = v_add(total, light);
+        else part[rayIndex % S] = v_add(part[rayIndex % S], light);
+    }
+    if (p->rngMode != RT_RNG_PCG) {
+        for (int step = 1; step < S; step <<= 1)
+            for (int k = 0; k < S; k += 2 * step) part[k] = v_add(part[k], part[k + step]);
+        total = part[0];
     }
     float n = (float)p->numRaysPerPixel;
     out[0] = total.x / n; out[1] = total.y / n; out[2] = total.z / n; out[3] = 1.0f;

@@ -46,6 +46,7 @@ void orc_display_srgb8(const float* rgba, uint32_t* out, size_t n_pixels);
 uint32_t orc_next_random(uint32_t* state);
 float    orc_random_value(uint32_t* state);
 void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int      orc_philox_substreams(int rays_per_pixel);      /* sub-streams of the Philox mode's estimator sum: 16 / 4 / 1 */
 float om_sin(float), om_cos(float), om_log(float), om_exp2(float), om_pow(float, float);
 float om_min(float, float), om_max(float, float);
 int   orc_hw_threads(void);

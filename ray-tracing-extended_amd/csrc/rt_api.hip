@@ -124,11 +124,13 @@ struct rt_ctx {
     int opt_bvh_reinsert = 0;       // BVH builder: insertion-based optimisation passes
     int opt_bvh_bins = 32, opt_bvh_cost_exp = 100;   // BVH builder: SAH bins per axis; exponent (percent) of the count in the SAH cost model
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
-    int opt_stream_stack = 31;      // k_stream: stack entries per lane kept in LDS (31 = five workgroups per CU); deeper BVHs spill the rest to global memory
+    int opt_stream_stack = 30;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory.  30 entries + the groups' item
+                                    // tables = 31,744 B per workgroup: five workgroups per CU (32,768 B already makes it four: measured -11 %)
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
     int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
     DevBuf<uint32_t> d_gstack;
+    DevBuf<float> d_park;              // k_stream, Philox mode: parked sub-stream sums
     DevBuf<uint32_t> d_wave_state;     // k_wave: path state of every wave's pixel slots
     int opt_refill_min = 16;        // k_wave: idle lanes that trigger a refill from the pending list
     int opt_wave_node_min = 24;     // k_wave: its node loop hands over to the leaves below this many descending lanes
@@ -298,7 +300,9 @@ int build_scene(rt_ctx* c)
     RT_UP(c->d_raw_range, range, uint32_t)
     RT_HIP(c, c->d_raw_tris.ensure(nt * 18));
     if (nt) RT_HIP(c, hipMemcpyAsync(c->d_raw_tris.p, c->h_tris.data(), nt * sizeof(rt_triangle), hipMemcpyHostToDevice, c->stream));
-    const float origin_mag = std::max(camera_magnitude(c->params), sphere_magnitude(c));
+    // headroom: the boxes are padded for ray origins up to twice as far out as the camera and the spheres are now (the term is
+    // 2e-6 * G), so a camera that drifts away from the geometry widens the padding (repad_boxes) once per doubling, not per frame
+    const float origin_mag = 2.0f * std::max(camera_magnitude(c->params), sphere_magnitude(c));
     c->stats.bvhBuiltOnDevice = 0;
     if (c->opt_device_bvh == 1 && nt > 0) {
         // the device builder takes every uploaded triangle; one that belongs to no chunk gets NaN records (k_relayout) and can never be hit
@@ -311,6 +315,7 @@ int build_scene(rt_ctx* c)
         rtbvh::build(pos.data(), 9, (uint32_t)live.size(), origin_mag, bvh_tuning(c), c->bvh);
         c->stats.lastBvhBuildMs = now_ms() - t0; c->stats.bvhBuilds++;
         c->n_nodes = c->bvh.nodes.size();
+        if (live.empty()) c->bvh.magnitude = origin_mag;        // no tree: only the trigger of repad_boxes looks at it
         const size_t nl = live.size();
         std::vector<float4> geo(3 * nl), nrm(3 * nl);
         for (size_t i = 0; i < nl; ++i) {
@@ -327,6 +332,10 @@ int build_scene(rt_ctx* c)
             nrm[3 * i + 2] = make_float4(t.normalC[0], t.normalC[1], t.normalC[2], 0.f);
         }
         RT_UP(c->d_tri_geo, geo, float4) RT_UP(c->d_tri_nrm, nrm, float4)
+        // BVH order -> uploaded triangle, on the device: what a later widening of the box padding (repad_boxes) refits from
+        std::vector<uint32_t> order_raw(nl);
+        for (size_t i = 0; i < nl; ++i) order_raw[i] = live[c->bvh.order[i]];
+        RT_UP(c->d_order, order_raw, uint32_t)
         RT_HIP(c, c->d_nodes.ensure(c->bvh.nodes.size() * 8));
         if (!c->bvh.nodes.empty())
             RT_HIP(c, hipMemcpyAsync(c->d_nodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(rtbvh::Node4),
@@ -341,6 +350,27 @@ int build_scene(rt_ctx* c)
     c->stats.numSpheres = (int)ns; c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->n_nodes; c->stats.bvhMaxStack = c->bvh.maxStack; c->stats.bvhInternalArea = c->area_at_build;
     c->scene_dirty = false; c->tile_order_valid = false;
+    return 0;
+}
+
+// World-space uploads: a ray origin (camera, defocus disc, sphere surface) has moved beyond the magnitude G the boxes were padded
+// for (pad = 3e-5 |coord| + 2e-6 G, bvh.cpp pad_box).  The tree stays: its boxes are refitted bottom-up from the uploaded triangles
+// with the new G (k_refit_level writes the same padded leaf boxes a build would) and the f16 form is derived again — a few small
+// launches instead of a host rebuild and a re-upload of every record.
+int repad_boxes(rt_ctx* c, float G)
+{
+    if (c->n_nodes && c->bvh.levelStart.size() >= 2) {
+        for (int L = (int)c->bvh.levelStart.size() - 2; L >= 0; --L) {
+            const uint32_t n0 = c->bvh.levelStart[L], n1 = c->bvh.levelStart[L + 1];
+            if (n1 > n0)
+                hipLaunchKernelGGL(rtg::k_refit_level, dim3(((n1 - n0) * 4 + 255) / 256), dim3(256), 0, c->stream,
+                                   reinterpret_cast<rtbvh::Node4*>(c->d_nodes.p), n0, n1, c->d_raw_tris.p, c->d_order.p, G);
+        }
+        RT_HIP(c, hipGetLastError());
+        { int r = compact_nodes(c); if (r) return r; }
+    }
+    c->bvh.magnitude = G;
+    c->stats.bvhRepads++;
     return 0;
 }
 
@@ -535,8 +565,11 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         if (c->scene_dirty) { int r = build_scene_local(c); if (r) return r; }
         else if (c->xf_dirty || local_scene_magnitude(c) > c->bvh.magnitude) { int r = run_geometry_kernels(c, true); if (r) return r; c->xf_dirty = false; }
     } else {
-        if (!c->scene_dirty && std::max(camera_magnitude(c->params), sphere_magnitude(c)) > c->bvh.magnitude) c->scene_dirty = true;   // re-pad the boxes
         if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
+        else {
+            const float om = std::max(camera_magnitude(c->params), sphere_magnitude(c));
+            if (om > c->bvh.magnitude) { int r = repad_boxes(c, 2.0f * om); if (r) return r; }     // widen the box padding, keep the tree
+        }
     }
     { int r = ensure_targets(c); if (r) return r; }
     if (c->target_pixels == 0 || n_frames == 0) return 0;
@@ -562,9 +595,14 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         const int tw = 1 << F.tile_w_log2, th = 64 >> F.tile_w_log2;
         F.tiles_x = (c->target_w + tw - 1) / tw; F.tiles_y = (c->target_rows + th - 1) / th;
     }
-    const bool philox = c->params.rngMode == RT_RNG_PHILOX;         // served by k_trace's Philox instantiation only
+    // the counter-based mode is k_stream's Philox instantiation whatever kernel was asked for (its estimator spreads a pixel's samples
+    // over the lanes of a wave); NumRaysPerPixel < 1 draws nothing in either mode and goes to k_trace
+    const bool philox = c->params.rngMode == RT_RNG_PHILOX && c->params.numRaysPerPixel >= 1;
     if (philox && var == Variant::Flat) return fail(c, -2, "the flat validation kernel implements the PCG stream only");
-    const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1;       // PCG or Philox instantiation
+    if (philox) kernel = 1;
+    if (philox && (c->target_w > 65535 || c->target_rows > 65535)) return fail(c, -7, "the Philox mode addresses at most 65535 x 65535 pixels per context");
+    const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1        // PCG or Philox instantiation
+                        && c->target_w <= 65535 && c->target_rows <= 65535;                          // (16-bit pixel coordinates in k_stream's item tables)
     const bool pooled = !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
     const bool waved = !philox && kernel == 3 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
@@ -574,7 +612,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const bool tile_kernel = !stream && !pooled && !waved && var != Variant::Flat;   // k_trace, PCG or Philox
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     if (tile_kernel) F.stack_cap = std::min(F.stack_cap, 64);        // a very deep tree spills past 64 entries instead of overflowing the LDS
-    // k_stream: at most opt_stream_stack entries per lane in LDS (31 = five workgroups per CU); a deeper worst case spills
+    // k_stream: at most opt_stream_stack entries per lane in LDS (30 = five workgroups per CU); a deeper worst case spills
     const bool stream_spill = stream && F.stack_cap > c->opt_stream_stack;
     if (stream_spill) F.stack_cap = c->opt_stream_stack;
     F.full_sort = c->opt_full_sort;
@@ -586,7 +624,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const size_t lds = var == Variant::Flat ? 0
                      : pooled ? (size_t)rtk::pool::wave_dwords(pool_cap) * sizeof(uint32_t) * rtk::kWavesPerBlock
                      : waved ? rtk::wv::wave_lds_bytes(F.stack_cap) * rtk::kWavesPerBlock
-                              : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock;
+                              : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock
+                                + (stream ? (size_t)rtk::kGroupMax * sizeof(uint2) * rtk::kWavesPerBlock : 0);     // k_stream: + the groups' item tables
     if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
     const bool counting = var == Variant::Counting;
     const bool compact = c->opt_compact_nodes != 0;            // k_trace / k_stream only; k_pool, k_wave and the flat twin read the f32 nodes
@@ -595,8 +634,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
                    : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
                    : stream ? rtk::stream_kernel(counting, philox, compact)       // instantiated in rt_stream_kernels.hip
                    : c->n_nodes == 0      // spheres only: the instantiation compiled for six waves per SIMD
-                            ? dispatch3(counting, philox, false, [](auto C, auto P, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, false, 6>; })
-                            : dispatch3(counting, philox, compact, [](auto C, auto P, auto H) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(P)::value, decltype(H)::value>; });
+                            ? dispatch3(counting, false, false, [](auto C, auto, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, false, 6>; })
+                            : dispatch3(counting, false, compact, [](auto C, auto, auto H) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(H)::value>; });
     if (lds > 64 * 1024) RT_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::kBlock, lds));
@@ -606,7 +645,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     // ... and k_wave waves 256: four tiles' worth (of any frame of the launch)
     const int frames_hint = waved ? std::max(1, std::min(n_frames, 8)) : 1;
     // work items of a multi-frame launch = tiles x frames: a thin strip (one rank of eight: 4,080 tiles) still fills every resident wave
-    const size_t frames_in_queue = (stream && c->opt_tile_sync && c->opt_frame_batch != 1) ? (size_t)std::max(1, std::min(n_frames, 64)) : 1;
+    // Philox mode: S = 16 / 4 / 1 sample lanes per pixel (the estimator's sub-streams, include/rt.h RT_RNG_PHILOX)
+    const int sample_lanes_log2 = !philox ? 0 : c->params.numRaysPerPixel >= 16 ? 4 : c->params.numRaysPerPixel >= 4 ? 2 : 0;
+    const bool stream_sync = stream && (c->opt_tile_sync || philox);       // k_stream taking whole work items (the Philox instantiation always does)
+    const size_t frames_in_queue = ((stream_sync && c->opt_frame_batch != 1) ? (size_t)std::max(1, std::min(n_frames, 64)) : 1) << sample_lanes_log2;
     const int want = pooled ? (ntiles + 2 * rtk::kWavesPerBlock - 1) / (2 * rtk::kWavesPerBlock)
                    : waved ? (int)(((size_t)ntiles * frames_hint + 4 * rtk::kWavesPerBlock - 1) / (4 * rtk::kWavesPerBlock))
                             : (int)std::min<size_t>(((size_t)ntiles * frames_in_queue + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock, (size_t)1 << 20);
@@ -615,8 +657,9 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     rtk::StreamArgs A{};
     A.shade_threshold = std::max(1, std::min(64, c->opt_shade_threshold));
     A.total_pixels = (unsigned int)ntiles * 64u;
-    A.tile_sync = c->opt_tile_sync;
-    A.tiles_per_fetch = std::max(1, std::min(64, c->opt_tiles_per_fetch));
+    A.tile_sync = stream_sync ? 1 : 0;
+    A.sample_lanes_log2 = sample_lanes_log2;
+    A.tiles_per_fetch = std::max(1, std::min(rtk::kGroupMax, c->opt_tiles_per_fetch));
     A.guide_div = 1;
     A.node_min = std::max(1, std::min(64, c->opt_node_min));
     rtk::PoolArgs PA{};
@@ -631,6 +674,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         WA.refill_min = std::max(1, std::min(64, c->opt_refill_min));
         WA.trav_min_lanes = std::max(1, std::min(64, c->opt_wave_trav_min));
         WA.node_min = std::max(1, std::min(64, c->opt_wave_node_min));
+    }
+    if (philox) {      // where the lanes park their sub-stream sums until the wave's group of items is done: [wave][item of the group][3][64]
+        RT_HIP(c, c->d_park.ensure((size_t)grid * rtk::kWavesPerBlock * (size_t)A.tiles_per_fetch * 192));
+        F.park = c->d_park.p;
     }
     if (stream_spill) {
         RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack + 3 - F.stack_cap) * PA.gstack_stride));
@@ -648,7 +695,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     // k_trace can trace several frames per launch (work items = (frame, tile)): the persistent waves then balance over
     // frames as well — what matters when a rank's strip has about as many tiles as the chip has wave slots.
     int batch = 1;
-    const bool stream_tiles = stream && c->opt_tile_sync;        // k_stream taking whole tiles: same (frame, tile) items as k_trace
+    const bool stream_tiles = stream_sync;                       // k_stream taking whole tiles: same (frame, tile) items as k_trace
     if ((tile_kernel || stream_tiles || waved) && n_frames > 1 && c->opt_frame_batch != 1) {
         const size_t budget = (size_t)4 << 30;                                  // <= 4 GiB of per-frame outputs (16 frames at 3840x2160)
         const size_t per_frame = c->target_pixels * sizeof(float4);
@@ -659,7 +706,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     }
     // LPT scheduling of the persistent waves: a launch records every tile's cost; the next ones hand tiles out costliest
     // first, so the end of a launch is filled with cheap tiles instead of waiting for a few expensive ones.
-    const bool lpt = (tile_kernel || (stream && c->opt_tile_sync) || waved) && c->opt_tile_lpt && ntiles > 1;
+    const bool lpt = (tile_kernel || stream_sync || waved) && c->opt_tile_lpt && ntiles > 1;
     c->lpt_active = lpt;
     bool record_costs = false;
     if (lpt) {
@@ -682,12 +729,12 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         if (stream_tiles) {
             // as many groups of 16 frames as fit, then groups of 4, the rest one by one — all in this one launch
             int rem = nb;
-            if (c->opt_stream_tile >= 4) { A.n16 = rem / 16; rem -= A.n16 * 16; }
-            if (c->opt_stream_tile >= 2) { A.n4 = rem / 4; rem -= A.n4 * 4; }
+            if (!philox && c->opt_stream_tile >= 4) { A.n16 = rem / 16; rem -= A.n16 * 16; }      // (Philox: sample lanes, not frames, fill a wave)
+            if (!philox && c->opt_stream_tile >= 2) { A.n4 = rem / 4; rem -= A.n4 * 4; }
             A.n1 = rem;
             // groups shrink towards the end of the launch (k_stream: guided self-scheduling): up to tiles_per_fetch items per fetch
             // while more than guide x (waves of the launch) x that many items are left
-            A.tiles_per_fetch = std::max(1, std::min(64, c->opt_tiles_per_fetch));
+            A.tiles_per_fetch = std::max(1, std::min(rtk::kGroupMax, c->opt_tiles_per_fetch));
             A.guide_div = std::max(1, grid * rtk::kWavesPerBlock * std::max(1, c->opt_fetch_guide));
         }
         F.frame = first_frame + i;
@@ -710,7 +757,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     }
     c->stats.lastFramesPerLaunch = batch;
     c->stats.lastKernel = var == Variant::Flat ? 4 : waved ? 3 : pooled ? 2 : stream ? 1 : 0;
-    c->stats.lastFramesInterleaved = stream ? (A.n16 ? 16 : A.n4 ? 4 : 1) : 1;
+    c->stats.lastFramesInterleaved = stream ? (philox ? 1 : A.n16 ? 16 : A.n4 ? 4 : 1) : 1;
+    c->stats.lastSampleLanes = philox ? 1 << sample_lanes_log2 : 1;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
@@ -752,7 +800,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
 {
     if (!c) return -1;
     const bool eligible = c->opt_kernel < 0 && var != Variant::Flat && c->have_params
-                          && c->params.numRaysPerPixel >= 1;
+                          && c->params.numRaysPerPixel >= 1 && c->params.rngMode != RT_RNG_PHILOX;   // (Philox: always k_stream)
     if (!eligible) {
         const int kernel = c->opt_kernel < 0 ? 0 : c->opt_kernel;
         // k_wave hands tiles out costliest first but cannot measure a tile's cost itself: k_trace traces the first frame
@@ -891,7 +939,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_park.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -16,6 +16,7 @@
 //     traversal stack lives in LDS (stack[entry][lane], one bank per lane, conflict-free);
 //   * accumulate (Accumulate.shader:43-54) is fused into the epilogue: 16 B read + 2 x 16 B write per pixel.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 #include "rt_math.hpp"
 #include "bvh.hpp"
@@ -59,6 +60,7 @@ struct FrameArgs {
     unsigned int gstack_stride; // lanes of the launch
     float4* out_frame;          // [nrows*W] currentFrame
     float4* accum;              // [nrows*W] resultTexture
+    float* park;                // k_stream, Philox mode: per wave [items of a group][3][64] sub-stream sums waiting for the estimator's tree; else null
     unsigned int* tile_counter;
     unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5]
 };
@@ -463,6 +465,7 @@ __device__ __forceinline__ const KA& fresh_kernargs()
 }
 static_assert(alignof(DeviceScene) <= 8 && alignof(FrameArgs) <= 8, "kernarg layout = struct layout");
 struct TraceKernArgs { DeviceScene S; FrameArgs F; };                     // k_trace(DeviceScene, FrameArgs)
+static_assert(offsetof(TraceKernArgs, F) == ((sizeof(DeviceScene) + 7) & ~size_t(7)), "kernarg layout = struct layout");
 // (k_trace's pixel loop is one shading-dominated region: the same treatment measured -0.8 % on the sphere workload and is not applied.)
 
 // frag :377-382 — one camera ray (4 RNG draws)
@@ -488,7 +491,7 @@ __device__ __forceinline__ void camera_ray(const rt_params& p, const Camera& c, 
 }
 
 // One pixel of one frame: frag :356-389 as a flat state machine (see file header).
-template <bool COUNT, bool FLAT, bool PHILOX, bool H = false>
+template <bool COUNT, bool FLAT, bool H = false>
 __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params& p, bool full_sort, bool fixed_origin, int frame, int x, int y,
                                            const TravStack& stk, Counters& cnt)
 {
@@ -497,9 +500,8 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
     Camera cam;
     cam.W = (float)W;
     const float uvx = ((float)x + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
-    typename std::conditional<PHILOX, rtm::PhiloxRng, uint32_t>::type rng;
-    if constexpr (PHILOX) rng.init((uint32_t)y * W + (uint32_t)x, (uint32_t)frame);
-    else rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)frame * 719393u;                 // :361-362
+    uint32_t rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)frame * 719393u;             // :361-362 (the reference's PCG stream; the
+                                                                                            // counter-based mode is k_stream's, rt_stream.hpp)
     {
         float lx = (uvx - 0.5f) * p.viewParams[0], ly = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * ly) + M[2]  * lz) + M[3]  * 1.0f,
@@ -599,12 +601,13 @@ __device__ __forceinline__ v3 render_pixel(const DeviceScene& S, const rt_params
 }
 
 constexpr int kBlock = 256;         // 4 waves
+constexpr int kGroupMax = 32;       // k_stream: most work items in a wave's group (the LDS table of their decoded positions: 256 B per wave)
 constexpr int kWavesPerBlock = kBlock / 64;
 
 // WAVES = waves per SIMD the register allocation aims at.  With a BVH the LDS stacks allow four workgroups per CU and the 95 VGPRs
 // the kernel takes by itself (five waves) are left alone (0); a scene of spheres only has no stack to speak of and is shading-bound:
 // six waves per SIMD (80 VGPRs) measure 37.3 Grays/s on the sphere workload against 34.9 at five and 33.7 at eight.
-template <bool COUNT, bool FLAT, bool PHILOX = false, bool H = false, int WAVES = 0>
+template <bool COUNT, bool FLAT, bool H = false, int WAVES = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES == 0 ? 1 : WAVES, WAVES == 0 ? 8 : WAVES))) void k_trace(DeviceScene S, FrameArgs F)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
         const int x = (tx << tw) + (lane & ((1 << tw) - 1)), ly = (ty << th) + (lane >> tw);
         if (x < F.p.width && ly < F.nrows) {
             const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
-            v3 c = render_pixel<COUNT, FLAT, PHILOX, H>(S, P, full_sort, fixed_origin, F.frame + (int)fi, x, y, stk, cnt);
+            v3 c = render_pixel<COUNT, FLAT, H>(S, P, full_sort, fixed_origin, F.frame + (int)fi, x, y, stk, cnt);
             const TraceKernArgs& KB = fresh_kernargs<TraceKernArgs>();
             const FrameArgs& F = KB.F;
             const size_t pi = (size_t)ly * F.p.width + x;

@@ -218,30 +218,38 @@ __device__ __forceinline__ float random_value(uint32_t& state)
 {
     return (float)next_random(state) * 2.3283064365386963e-10f;   // r / 2^32 (the shader's 4294967295.0 is a float32 literal)
 }
-// ---- counter-based alternative (rt_params.rngMode = RT_RNG_PHILOX): Philox4x32-10, key (pixelIndex, Frame); draw number i
-// of the pixel (in the shader's draw order) is word i&3 of block i>>2.  Four words are kept in registers and shifted out.
-struct PhiloxRng {
-    uint32_t i, k0, k1, v0, v1, v2, v3;
-    __device__ __forceinline__ void init(uint32_t pixelIndex, uint32_t frame) { i = 0; k0 = pixelIndex; k1 = frame; v0 = v1 = v2 = v3 = 0; }
-    __device__ __forceinline__ void block()
+// ---- counter-based alternative (rt_params.rngMode = RT_RNG_PHILOX): Philox4x32-10, key (pixelIndex, Frame), counter (block, sample,
+// 0, 0).  Every draw is addressed by what it is for — block 0: the sample's camera ray (4 draws); blocks 1 + 2b and 2 + 2b: the hit at
+// loop index b of Trace (8 draws) — so the samples of a pixel are independent and can sit on different lanes (k_stream<.., PHILOX>;
+// the definition is include/rt.h RT_RNG_PHILOX).  A PhiloxScope serves the draws of ONE such site: it lives in a straight-line
+// region, n is a compile-time constant at every use after inlining, and nothing of the generator survives the region (no RNG state
+// in the persistent loop's registers).
+struct PhiloxScope {
+    uint32_t k0, k1, c1, block, n;
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ void begin(uint32_t pixelIndex, uint32_t frame, uint32_t sample, uint32_t first_block)
     {
-        uint32_t c0 = i >> 2, c1 = 0, c2 = 0, c3 = 0, a = k0, b = k1;
+        k0 = pixelIndex; k1 = frame; c1 = sample; block = first_block; n = 0; w0 = w1 = w2 = w3 = 0;
+    }
+    __device__ __forceinline__ void gen(uint32_t blk)
+    {
+        uint32_t c0 = blk, d1 = c1, c2 = 0, c3 = 0, a = k0, b = k1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
             const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
             const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-            c0 = hi1 ^ c1 ^ a; c1 = lo1; c2 = hi0 ^ c3 ^ b; c3 = lo0;
+            c0 = hi1 ^ d1 ^ a; d1 = lo1; c2 = hi0 ^ c3 ^ b; c3 = lo0;
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
-        v0 = c0; v1 = c1; v2 = c2; v3 = c3;
+        w0 = c0; w1 = d1; w2 = c2; w3 = c3;
     }
 };
-__device__ __forceinline__ float random_value(PhiloxRng& g)
+__device__ __forceinline__ float random_value(PhiloxScope& g)
 {
-    if ((g.i & 3u) == 0u) g.block();
-    const uint32_t r = g.v0;
-    g.v0 = g.v1; g.v1 = g.v2; g.v2 = g.v3;
-    g.i++;
+    const uint32_t q = g.n & 3u;
+    if (q == 0u) g.gen(g.block + (g.n >> 2));
+    const uint32_t r = q == 0u ? g.w0 : q == 1u ? g.w1 : q == 2u ? g.w2 : g.w3;
+    g.n++;
     return (float)r * 2.3283064365386963e-10f;
 }
 

@@ -37,12 +37,22 @@ struct StreamArgs {
                                 // group, pixel of the sub-tile).  Frames are independent (frag :362 seeds by Frame), so the same pixel
                                 // in 16 or 4 frames gives a wave rays that start almost identical and per-lane costs that are
                                 // identically distributed
+    int sample_lanes_log2;      // PHILOX instantiations: log2 S of the sample lanes per pixel (4 / 2 / 0 for NumRaysPerPixel >= 16 / >= 4 / else).
+                                // The counter-based stream makes a pixel's samples independent, so a work item is a 2x2 / 4x4 / 8x8
+                                // sub-tile of ONE frame whose pixels are spread over S lanes each: lane = (sample lane k, pixel of the
+                                // sub-tile); lane k traces samples k, k + S, k + 2S, ... and the S partial sums meet in a fixed tree
+                                // (the estimator of include/rt.h RT_RNG_PHILOX).  n1 = frames of the launch, n16 = n4 = 0
 };
 
 enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
+constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 
 struct StreamKernArgs { DeviceScene S; FrameArgs F; StreamArgs A; };     // k_stream's argument segment (fresh_kernargs, rt_kernels.hpp)
 static_assert(alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
+// every by-value argument starts on the next multiple of 8 bytes in the kernarg segment; the struct view must put its members there too
+// (tests/test_kernarg_layout_cpu.py reads the offsets back from the code object)
+static_assert(offsetof(StreamKernArgs, F) == ((sizeof(DeviceScene) + 7) & ~size_t(7))
+              && offsetof(StreamKernArgs, A) == ((offsetof(StreamKernArgs, F) + sizeof(FrameArgs) + 7) & ~size_t(7)), "kernarg layout = struct layout");
 
 template <bool COUNT, bool PHILOX = false, bool H = false>
 // Five waves per SIMD (96 VGPRs: 95 used, no scratch; LDS stack of <= 31 entries per lane so that five workgroups fit a CU): the
@@ -82,15 +92,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         if (depth >= capb) v = gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride];
         return v;
     };
+    // The work items of the wave's current group, decoded once per group (one lane per item) into LDS behind the stacks: per item
+    // (x0 | y0 << 16) of its sub-tile's first pixel (local rows) and (first frame | log2 frames or sample lanes << 28).  A lane that
+    // takes a unit of the group reads its item's entry instead of redoing the divisions of `decode` in every SHADE pass.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    using lds_u2 = __attribute__((address_space(3))) u32x2;
+    lds_u2* const item_tab = reinterpret_cast<lds_u2*>((uintptr_t)__builtin_amdgcn_readfirstlane(
+                                 (uint32_t)(uintptr_t)(lds_u32*)(lds_stack + (size_t)kWavesPerBlock * F.stack_cap * 64) + (uint32_t)wave * (kGroupMax * 8u)));
     Counters cnt = {};
     const float INF = __builtin_inff();
+    // PHILOX: where the sums of the sub-streams of item k of the wave's group are parked: wave-private, [item][channel][position in the item]
+    // (computed where it is used, from the region's own view of the arguments: no pointer held across the persistent loop)
+    auto park_slot = [&](const FrameArgs& F, const StreamArgs& A, unsigned int k) -> float* {
+        return F.park + (((size_t)(blockIdx.x * kWavesPerBlock) + (threadIdx.x >> 6)) * (unsigned)A.tiles_per_fetch + k) * 192u;
+    };
 
     // ---- per-lane state -------------------------------------------------------------------------------------
     uint32_t mode = A.tile_sync ? kModeWait : kModeShade;   // every lane starts by asking for a pixel (or the wave for a tile)
     bool fresh = false;                 // the lane was just given a pixel: its first camera ray is due
-    int px = -1, ly = 0;                // current pixel (px < 0: none)
-    typename std::conditional<PHILOX, rtm::PhiloxRng, uint32_t>::type rng;        // RT_RNG_PCG: the reference's stream; RT_RNG_PHILOX: counter-based
-    if constexpr (PHILOX) rng.init(0u, 0u); else rng = 0u;
+    uint32_t pxy = kNoPixel;            // current pixel: x | local row << 16 (the host keeps k_stream to targets of at most 65535 x 65535); kNoPixel: none
+    uint32_t rng = 0u;                  // RT_RNG_PCG: the reference's stream, a serial chain through the pixel's samples and bounces.  RT_RNG_PHILOX keeps
+                                        // no generator state at all: a draw is a function of (pixel, frame, sample, bounce) — rtm::PhiloxScope
     int sample = 0, bounce = 0;
     v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
     RaySlabT<H> slab = make_slab<H>(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
@@ -99,7 +121,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
     unsigned int wave_fi = 0;           // frame (offset into the launch) of this lane's pixel
     unsigned long long wave_t0 = 0;
-    unsigned int group_base = 0, group_len = 0, kidx = 0;   // items [group_base, group_base + group_len) belong to this wave; kidx: this lane's
+    unsigned int group_base = 0, group_len = 0;   // items [group_base, group_base + group_len) of the launch's queue belong to this wave
+    unsigned int next_unit = 0;                   // ... = 64 * group_len units (item of the group << 6 | position in the item); units below this are taken.
+                                                  // Wave-uniform: only ever changed in wave-uniform control flow
+    unsigned int kidx = 0;                        // this lane's unit
+    // A unit is what one lane works through before it needs new work: PCG — a pixel of the item with all its samples (the RNG chain);
+    // PHILOX — one sub-stream (samples k, k + S, ...) of a pixel.  Units are handed out in order to whichever lanes ask (take_units):
+    // the lanes at work always hold a window of consecutive units — neighbouring pixels, the same few items — and the group ends within
+    // one unit's time for every lane instead of behind the lane that happened to draw the most expensive units.
 
     // Give this lane its position's pixel of work item `item` = (frame, tile); false when the tile has no pixel there.
     // Work items: frame group (16, 4 or 1 frames) x 8x8 tile (costliest first) x sub-tile of the tile.  The frames of a launch are
@@ -111,6 +140,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
     // launch ends on the cheap tiles of its most efficient items.
     auto decode = [](const FrameArgs& F, const StreamArgs& A, unsigned int item, unsigned int& tile, unsigned int& sub, unsigned int& frame0) -> int {
         const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
+        if constexpr (PHILOX) {
+            // sample lanes instead of frames: every item lies in one frame (frame0), frame-major queue
+            const int sgl = A.sample_lanes_log2;
+            const unsigned int per_frame = ntiles_ << sgl;
+            const unsigned int g = item / per_frame, r = item - g * per_frame;
+            tile = r >> sgl; sub = r & ((1u << sgl) - 1u); frame0 = g;
+            return sgl;
+        }
         const unsigned int items1_ = (unsigned)A.n1 * ntiles_, items4_ = (unsigned)A.n4 * (ntiles_ << 2);
         int fgl = 0; unsigned int fbase = (unsigned)A.n16 * 16u + (unsigned)A.n4 * 4u;
         if (item >= items1_) { item -= items1_; fgl = 2; fbase = (unsigned)A.n16 * 16u; if (item >= items4_) { item -= items4_; fgl = 4; fbase = 0u; } }
@@ -119,26 +156,48 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         tile = r >> fgl; sub = r & ((1u << fgl) - 1u); frame0 = fbase + (g << fgl);
         return fgl;
     };
-    auto start_pixel = [&](const FrameArgs& F, const StreamArgs& A, unsigned int item) -> bool {
+    auto pixel_index = [&](const FrameArgs& F) -> uint32_t {      // frag :360-361 of this lane's pixel (global coordinates)
+        const int ly = (int)(pxy >> 16);
+        return (uint32_t)(F.row0 + (ly >> 3) * F.row_stride + (ly & 7)) * (uint32_t)F.p.width + (pxy & 0xFFFFu);
+    };
+    // Give this lane unit `id` of the group; false when the item has no pixel there (image edge, frame count).
+    auto start_pixel = [&](const FrameArgs& F, const StreamArgs& A, unsigned int id) -> bool {
         const rt_params& p = F.p;
         const uint32_t W = (uint32_t)p.width;
         const unsigned int nframes_ = (unsigned)(A.n16 * 16 + A.n4 * 4 + A.n1);
-        unsigned int tile, sub, frame0;
-        const int fgl = decode(F, A, item, tile, sub, frame0);
+        const u32x2 e = item_tab[id >> 6];
+        const unsigned int pos = id & 63u;
+        const int fgl = (int)(e.y >> 28);
+        const unsigned int frame0 = e.y & 0x0FFFFFFFu;
         const int pxl = 6 - fgl, swl = pxl >> 1;              // log2 of: pixels per sub-tile, sub-tile width
-        if (F.tile_order) tile = F.tile_order[tile];
-        const unsigned int pix = (unsigned)lane & ((1u << pxl) - 1u);
-        const unsigned int fi = frame0 + ((unsigned)lane >> pxl);
-        const int x = (int)((tile % (unsigned)F.tiles_x) * 8u + ((sub & ((1u << (3 - swl)) - 1u)) << swl) + (pix & ((1u << swl) - 1u)));
-        const int yy = (int)((tile / (unsigned)F.tiles_x) * 8u + ((sub >> (3 - swl)) << swl) + (pix >> swl));
+        const unsigned int pix = pos & ((1u << pxl) - 1u);
+        const unsigned int fi = PHILOX ? frame0 : frame0 + (pos >> pxl);
+        const int x = (int)((e.x & 0xFFFFu) + (pix & ((1u << swl) - 1u)));
+        const int yy = (int)((e.x >> 16) + (pix >> swl));
         if (!(x < p.width && yy < F.nrows && fi < nframes_)) return false;
-        px = x; ly = yy; wave_fi = fi;
+        pxy = (uint32_t)x | ((uint32_t)yy << 16); wave_fi = fi; kidx = id;
         const uint32_t pixelIndex = (uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x;
-        if constexpr (PHILOX) rng.init(pixelIndex, (uint32_t)(F.frame + (int)fi));
-        else rng = pixelIndex + (uint32_t)(F.frame + (int)fi) * 719393u;                    // :361-362
+        if constexpr (PHILOX) sample = (int)(pos >> pxl);                                    // this unit's sub-stream: samples k, k + S, ... (S <= NumRaysPerPixel)
+        else { rng = pixelIndex + (uint32_t)(F.frame + (int)fi) * 719393u; sample = 0; }     // :361-362
         total = rtm::mk(0.f, 0.f, 0.f);
-        sample = 0; live = false;
+        live = false;
         return true;
+    };
+    // Lanes with `want` take the next units of the group, in lane order; true for a lane that got one.  Call in wave-uniform control
+    // flow only (next_unit must stay uniform).  Units without a pixel are skipped by asking again.
+    auto take_units = [&](const FrameArgs& F, const StreamArgs& A, bool want) -> bool {
+        bool got = false;
+        const unsigned int total_units = group_len << 6;
+        for (;;) {
+            const unsigned long long need = ballot_(want);
+            if (need == 0ull || next_unit >= total_units) break;
+            if (want) {
+                const unsigned int id = next_unit + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                if (id < total_units && start_pixel(F, A, id)) { want = false; got = true; }
+            }
+            next_unit = __builtin_amdgcn_readfirstlane(min(total_units, next_unit + (unsigned int)__popcll(need)));
+        }
+        return got;
     };
 
     for (;;) {
@@ -149,15 +208,57 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
             const unsigned int ntiles_ = (unsigned)(F.tiles_x * F.tiles_y);
-            const unsigned int nitems_ = (unsigned)A.n1 * ntiles_ + (unsigned)A.n4 * (ntiles_ << 2) + (unsigned)A.n16 * (ntiles_ << 4);
-            if (F.tile_cost && group_len != 0 && lane == 0) {
-                const uint32_t share = (uint32_t)(((__builtin_readcyclecounter() - wave_t0) >> 6) / group_len);
+            const unsigned int nitems_ = PHILOX ? (unsigned)A.n1 * (ntiles_ << A.sample_lanes_log2)
+                                                : (unsigned)A.n1 * ntiles_ + (unsigned)A.n4 * (ntiles_ << 2) + (unsigned)A.n16 * (ntiles_ << 4);
+            if constexpr (PHILOX) {
+                // ---- the estimator's tree (include/rt.h RT_RNG_PHILOX): every lane parked the sum of its sub-stream for each item of the group;
+                // the S sample lanes of a pixel now add them pairwise across the wave — (k, k + 1), then (k, k + 2), ... : lane offsets
+                // 2^pxl, 2^(pxl+1), ... — and sample lane 0 divides by NumRaysPerPixel and stores the pixel (frag :387-388, Accumulate)
+                const int pxl = 6 - A.sample_lanes_log2, swl = pxl >> 1;
+                const uint32_t W = (uint32_t)F.p.width;
+                const float nf = (float)F.p.numRaysPerPixel;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every lane's parked sums have left the wave
                 for (unsigned int k = 0; k < group_len; ++k) {
-                    unsigned int t, sub_, f0_;
-                    (void)decode(F, A, group_base + k, t, sub_, f0_);
-                    if (F.tile_order) t = F.tile_order[t];
-                    atomicAdd(&F.tile_cost[t], share);
+                    const u32x2 e = item_tab[k];
+                    const unsigned int fi = e.y & 0x0FFFFFFFu;
+                    const unsigned int pix = (unsigned)lane & ((1u << pxl) - 1u);
+                    const int x = (int)((e.x & 0xFFFFu) + (pix & ((1u << swl) - 1u)));
+                    const int yy = (int)((e.x >> 16) + (pix >> swl));
+                    const bool present = x < F.p.width && yy < F.nrows;
+                    float tx = 0.f, ty = 0.f, tz = 0.f;
+                    if (present) {          // (parked by whichever lane worked the unit: read past the L1)
+                        const float* q = park_slot(F, A, k) + lane;
+                        tx = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ty = __hip_atomic_load(q + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tz = __hip_atomic_load(q + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    for (int off = 1 << pxl; off < 64; off <<= 1) {
+                        tx = tx + __shfl_xor(tx, off, 64); ty = ty + __shfl_xor(ty, off, 64); tz = tz + __shfl_xor(tz, off, 64);
+                    }
+                    if (present && ((unsigned)lane >> pxl) == 0u) {
+                        const float cx = tx / nf, cy = ty / nf, cz = tz / nf;
+                        const size_t pi = (size_t)yy * W + (uint32_t)x;
+                        F.out_frame[(size_t)fi * F.frame_stride + pi] = make_float4(cx, cy, cz, 1.0f);
+                        if (F.frames_in_launch <= 1) {
+                            const float weight = 1.0f / (float)(F.frame + 1);              // Accumulate.shader:48
+                            const float omw = 1.0f - weight;
+                            const float4 prev = F.accum[pi];
+                            float4 acc;
+                            acc.x = rtm::saturate(prev.x * omw + cx * weight);
+                            acc.y = rtm::saturate(prev.y * omw + cy * weight);
+                            acc.z = rtm::saturate(prev.z * omw + cz * weight);
+                            acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
+                            F.accum[pi] = acc;
+                        }
+                    }
                 }
+            }
+            uint32_t slot = (uint32_t)lane;
+            asm volatile("" : "+v"(slot));                  // (keeps the table address out of the persistent loop's registers)
+            if (F.tile_cost && group_len != 0 && slot < group_len) {
+                const uint32_t share = (uint32_t)(((__builtin_readcyclecounter() - wave_t0) >> 6) / group_len);
+                const u32x2 e = item_tab[slot];                                        // lane k: item k of the group
+                atomicAdd(&F.tile_cost[((e.x >> 16) >> 3) * (unsigned)F.tiles_x + ((e.x & 0xFFFFu) >> 3)], share);
             }
             // guided self-scheduling: groups of up to tiles_per_fetch items while plenty of work is left (lanes flow from one item to
             // the next instead of idling behind the item's slowest pixel), single items near the end of the launch (balance)
@@ -174,9 +275,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             if (group_base >= nitems_) break;
             group_len = min(K, nitems_ - group_base);
             wave_t0 = __builtin_readcyclecounter();
-            kidx = 0;
-            while (kidx < group_len && !start_pixel(F, A, group_base + kidx)) ++kidx;
-            if (kidx < group_len) { fresh = true; mode = kModeShade; }
+            if (slot < group_len) {                                                    // lane k decodes item k of the group
+                unsigned int tile, sub, frame0;
+                const int fgl = decode(F, A, group_base + slot, tile, sub, frame0);
+                const int swl = (6 - fgl) >> 1;
+                if (F.tile_order) tile = F.tile_order[tile];
+                const unsigned int x0 = (tile % (unsigned)F.tiles_x) * 8u + ((sub & ((1u << (3 - swl)) - 1u)) << swl);
+                const unsigned int y0 = (tile / (unsigned)F.tiles_x) * 8u + ((sub >> (3 - swl)) << swl);
+                item_tab[slot] = u32x2{ x0 | (y0 << 16), frame0 | ((unsigned)fgl << 28) };
+            }
+            next_unit = 0;
+            if (take_units(F, A, true)) { fresh = true; mode = kModeShade; }
             continue;
         }
 
@@ -197,8 +306,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
             const rt_params& p = F.p;
             const float* M = p.camLocalToWorld;
             const uint32_t W = (uint32_t)p.width;
+            bool need_ray = false;                      // a camera ray must be generated
+            bool want = false;                          // this lane finished its unit and takes the next one of the group
             if (mode == kModeShade) {
-                bool need_ray = fresh;                  // a camera ray must be generated
+                need_ray = fresh;
                 fresh = false;
                 bool path_done = false;
                 if (live) {
@@ -233,18 +344,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             skip = true;
                         }
                         if (!skip) {
-                            const bool isSpecular = mprm.z >= rtm::random_value(rng);  // :325
-                            const float specF = isSpecular ? 1.0f : 0.0f;
-                            o = hitPoint;                                              // :327
-                            v3 diffuseDir = rtm::normalize(normal + rtm::random_direction(rng));
-                            v3 specularDir = rtm::reflect(d, normal);
-                            d = rtm::normalize(rtm::lerp(diffuseDir, specularDir, mprm.y * specF));
-                            v3 emitted = rtm::mk(memi.x, memi.y, memi.z) * mprm.x;     // :333-335
-                            light = light + emitted * rayColour;
-                            rayColour = rayColour * rtm::lerp(colour, rtm::mk(mspec.x, mspec.y, mspec.z), specF);
-                            float pr = rtm::fmax_(rayColour.x, rtm::fmax_(rayColour.y, rayColour.z));   // :338-342
-                            if (rtm::random_value(rng) >= pr) path_done = true;
-                            else { float ip = rtm::rcp_(pr); rayColour = rayColour * ip; }
+                            auto scatter = [&](auto& R) {
+                                const bool isSpecular = mprm.z >= rtm::random_value(R);    // :325
+                                const float specF = isSpecular ? 1.0f : 0.0f;
+                                o = hitPoint;                                              // :327
+                                v3 diffuseDir = rtm::normalize(normal + rtm::random_direction(R));
+                                v3 specularDir = rtm::reflect(d, normal);
+                                d = rtm::normalize(rtm::lerp(diffuseDir, specularDir, mprm.y * specF));
+                                v3 emitted = rtm::mk(memi.x, memi.y, memi.z) * mprm.x;     // :333-335
+                                light = light + emitted * rayColour;
+                                rayColour = rayColour * rtm::lerp(colour, rtm::mk(mspec.x, mspec.y, mspec.z), specF);
+                                float pr = rtm::fmax_(rayColour.x, rtm::fmax_(rayColour.y, rayColour.z));   // :338-342
+                                if (rtm::random_value(R) >= pr) path_done = true;
+                                else { float ip = rtm::rcp_(pr); rayColour = rayColour * ip; }
+                            };
+                            if constexpr (PHILOX) {
+                                rtm::PhiloxScope R;                                        // the eight draws of this hit: blocks 1 + 2b, 2 + 2b
+                                R.begin(pixel_index(F), (uint32_t)(F.frame + (int)wave_fi), (uint32_t)sample, 1u + 2u * (uint32_t)bounce);
+                                scatter(R);
+                            } else scatter(rng);
                         }
                         ++bounce;
                         if (bounce > p.maxBounceCount) path_done = true;               // loop bound :305
@@ -257,13 +375,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                     }
                     if (path_done) {
                         total = total + light;                                         // :384
-                        ++sample;
-                        if (sample >= p.numRaysPerPixel) {
+                        sample += PHILOX ? (1 << A.sample_lanes_log2) : 1;
+                        if (PHILOX && sample >= p.numRaysPerPixel) {
+                            // ---- this unit (one sub-stream of a pixel) is complete: park its sum (the wave adds the sub-streams up when the
+                            // group is done) and ask for the next unit
+                            float* q = park_slot(F, A, kidx >> 6) + (kidx & 63u);
+                            q[0] = total.x; q[64] = total.y; q[128] = total.z;
+                            pxy = kNoPixel; want = true;
+                        } else if (sample >= p.numRaysPerPixel) {
                             // ---- pixel complete: frag :387-388 + Accumulate.shader:45-50
                             const float n = (float)p.numRaysPerPixel;
                             const float cx = total.x / n, cy = total.y / n, cz = total.z / n;
-                            const size_t pi = (size_t)ly * W + (uint32_t)px;
-                            F.out_frame[(size_t)wave_fi * F.frame_stride + pi] = make_float4(cx, cy, cz, 1.0f);
+                            const size_t pi = (size_t)(pxy >> 16) * W + (pxy & 0xFFFFu);
+                            float one = 1.0f;
+                            asm volatile("" : "+v"(one));       // (or the 16-byte register tuple of this store is set up, w = 1, at kernel entry and spilled)
+                            F.out_frame[(size_t)wave_fi * F.frame_stride + pi] = make_float4(cx, cy, cz, one);
                             if (F.frames_in_launch <= 1) {
                                 const float weight = 1.0f / (float)(F.frame + 1);              // Accumulate.shader:48
                                 const float omw = 1.0f - weight;
@@ -275,22 +401,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                                 acc.w = rtm::saturate(prev.w * omw + 1.0f * weight);
                                 F.accum[pi] = acc;
                             }
-                            px = -1;
-                            if (A.tile_sync) {
-                                // on to this lane's position in the next tile of the wave's group; idle only when the group is done
-                                ++kidx;
-                                while (kidx < group_len && !start_pixel(F, A, group_base + kidx)) ++kidx;
-                                if (kidx < group_len) need_ray = true; else mode = kModeWait;
-                            }
+                            pxy = kNoPixel; want = A.tile_sync != 0;
                         } else need_ray = true;
                     }
                     live = false;
                 }
+            }
+            // ---- lanes that finished their unit take the group's next units (wave-uniform control flow); idle (WAIT) once the group has none left
+            if (ballot_(want) != 0ull) {
+                const bool got = take_units(F, A, want);
+                if (want) { if (got) need_ray = true; else mode = kModeWait; }
+            }
+            if (mode == kModeShade) {
                 // ---- pixel refill: tile-major global order; indices outside the strip are skipped
-                while (!A.tile_sync) {
-                    const unsigned long long need = ballot_(px < 0 && mode != kModeDead);
+                while (!PHILOX && !A.tile_sync) {
+                    const unsigned long long need = ballot_(pxy == kNoPixel && mode != kModeDead);
                     if (need == 0) break;
-                    if (px < 0 && mode != kModeDead) {
+                    if (pxy == kNoPixel && mode != kModeDead) {
                         unsigned int base = 0;
                         const int first = __builtin_ctzll(need);
                         if (lane == first) base = atomicAdd(F.tile_counter, (unsigned int)__popcll(need));
@@ -302,10 +429,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             const int x = (int)(tile % (unsigned)F.tiles_x) * 8 + (int)(within & 7u);
                             const int yy = (int)(tile / (unsigned)F.tiles_x) * 8 + (int)(within >> 3);
                             if (x < p.width && yy < F.nrows) {
-                                px = x; ly = yy;
+                                pxy = (uint32_t)x | ((uint32_t)yy << 16);
                                 const int y = F.row0 + (yy >> 3) * F.row_stride + (yy & 7);
-                                if constexpr (PHILOX) rng.init((uint32_t)y * W + (uint32_t)x, (uint32_t)F.frame);
-                                else rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;      // :361-362
+                                rng = ((uint32_t)y * W + (uint32_t)x) + (uint32_t)F.frame * 719393u;      // :361-362
                                 total = rtm::mk(0.f, 0.f, 0.f);
                                 sample = 0;
                                 need_ray = true;        // (numRaysPerPixel < 1 is routed to k_trace by the host)
@@ -324,13 +450,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         cam.right = rtm::mk(M[0], M[4], M[8]);
                         cam.up    = rtm::mk(M[1], M[5], M[9]);
                         cam.pos   = ld3(p.worldSpaceCameraPos);
+                        const int px = (int)(pxy & 0xFFFFu), ly = (int)(pxy >> 16);
                         const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
                         const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
                         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,
                                                  ((M[4] * lx + M[5] * lyv) + M[6]  * lz) + M[7]  * 1.0f,
                                                  ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f);
-                        camera_ray(p, cam, rng, o, d, F.fixed_origin != 0);
+                        if constexpr (PHILOX) {
+                            rtm::PhiloxScope R;                                        // the four draws of this sample's camera ray: block 0
+                            R.begin((uint32_t)y * W + (uint32_t)px, (uint32_t)(F.frame + (int)wave_fi), (uint32_t)sample, 0u);
+                            camera_ray(p, cam, R, o, d, F.fixed_origin != 0);
+                        } else camera_ray(p, cam, rng, o, d, F.fixed_origin != 0);
                         bounce = 0;
                         rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
                     }

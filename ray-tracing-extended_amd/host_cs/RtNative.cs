@@ -126,6 +126,8 @@ namespace RtMi355x
         public int bvhBuiltOnDevice;
         public int bvhBuilds;
         public int bvhRebuilds;
+        public int bvhRepads;
+        public int lastSampleLanes;
         public int _reserved;
     }
 

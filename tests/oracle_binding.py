@@ -46,6 +46,8 @@ class Oracle:
         L.orc_display_srgb8.restype = None
         L.orc_display_srgb8.argtypes = [POINTER(c_float), c_void_p, c_size_t]
         L.orc_hw_threads.restype = c_int
+        L.orc_philox_substreams.restype = c_int
+        L.orc_philox_substreams.argtypes = [c_int]
         L.orc_set_accel.restype = None
         L.orc_set_accel.argtypes = [c_int]
 

@@ -245,3 +245,39 @@ def test_automatic_kernel_choice_without_the_costliest_first_order(rtx, oracle, 
         tracer.set_option("tile_lpt", 1)
     want, _, _ = oracle.render(*b, 0, 17)
     assert_bitwise(acc, want, "auto kernel, tile_lpt = 0")
+
+
+def test_camera_drifting_away_from_the_geometry_widens_the_padding_without_a_rebuild(rtx, oracle, tracer):
+    """World-space uploads: the BVH boxes are padded for ray origins up to a magnitude G (camera, spheres, triangles).  A camera
+    beyond the triangles' extent that keeps moving outward used to rebuild the whole scene on the host every frame; now the
+    padding has headroom (2x) and is widened on the device (refit + f16 nodes) once per doubling: no BVH build, image == oracle."""
+    h = rtx.host
+    m = rtx.scenes.mesh_test_scene(64, 40)
+    m.numRaysPerPixel, m.maxBounceCount = 2, 3
+    b = m.build_buffers()
+    params, spheres, tris, infos = b
+    extent = float(np.abs(np.concatenate([tris["posA"], tris["posB"], tris["posC"]])).max()) if len(tris) else 1.0
+    for k in (0, 1):
+        tracer.set_option("kernel", k)
+        tracer.set_rows(0, int(params["height"]))
+        tracer.upload(spheres=spheres[:0], triangles=tris, meshinfo=infos)
+        builds0 = repads0 = None
+        dist = 1.5 * extent
+        for step in range(7):                                  # 1.5x, 1.95x, ... 7.2x the extent: a few doublings
+            p = params.copy()
+            pos = np.float32([0.3, 1.0 + 0.1 * step, -dist])
+            p["worldSpaceCameraPos"] = pos
+            mtx = p["camLocalToWorld"].copy(); mtx[3], mtx[7], mtx[11] = pos; p["camLocalToWorld"] = mtx
+            tracer.set_params(p)
+            tracer.reset_accum()
+            tracer.render_frame(step)
+            got = tracer.read_last_frame()
+            st = tracer.stats()
+            if builds0 is None:
+                builds0, repads0 = st["bvhBuilds"], st["bvhRepads"]
+            want, _ = oracle.render_frame(p, spheres[:0], tris, infos, step)
+            assert_bitwise(got, want, f"kernel {k}, camera at {dist / extent:.2f}x the extent")
+            assert st["bvhBuilds"] == builds0, f"camera drift triggered a BVH build at step {step}"
+            dist *= 1.3
+        assert 1 <= st["bvhRepads"] - repads0 <= 3, st["bvhRepads"] - repads0
+    tracer.set_option("kernel", 0)

@@ -163,7 +163,7 @@ def test_stream_stack_spill_does_not_change_the_image(rtx, tracer, stream_stack)
         got, got_last = run_gpu(tracer, b, 2, 2, kernel=1)
         rays = tracer.stats()["rays"]
     finally:
-        tracer.set_option("stream_stack", 31)
+        tracer.set_option("stream_stack", 30)
     assert_bitwise(got_last, ref_last, f"stream(stack={stream_stack}) vs tile kernel, last frame")
     assert_bitwise(got, ref, f"stream(stack={stream_stack}) vs tile kernel, accum")
     assert rays == rays_ref
@@ -224,44 +224,95 @@ def test_display_srgb8_matches_oracle(rtx, oracle, tracer, tmp_path):
     assert (tmp_path / "c1.png").stat().st_size > 1000
 
 
+def _philox(buffers, rays=None, **extra):
+    params, spheres, tris, infos = buffers
+    params = params.copy()
+    params["rngMode"] = 1
+    if rays is not None:
+        params["numRaysPerPixel"] = rays
+    for k, v in extra.items():
+        params[k] = v
+    return params, spheres, tris, infos
+
+
 @pytest.mark.parametrize("scene", ["spheres", "mesh"])
-def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene):
-    """rt_params.rngMode = RT_RNG_PHILOX (counter-based Philox4x32-10, key = (pixelIndex, Frame)): GPU == oracle twin."""
-    m = rtx.scenes.config1(96, 64) if scene == "spheres" else rtx.scenes.mesh_test_scene(96, 64)
-    params, spheres, tris, infos = m.build_buffers()
-    params = params.copy()
-    params["rngMode"] = 1
-    b = (params, spheres, tris, infos)
-    want, want_last, _ = oracle.render(*b, 3, 2)
-    for kernel in (0, 1, 2, -1):                # k_trace<PHILOX>, k_stream<PHILOX>; option 2 falls back to k_trace's; automatic choice
-        acc, last = run_gpu(tracer, b, 3, 2 if kernel >= 0 else 5, kernel=kernel)
-        if kernel < 0:
-            want, want_last, _ = oracle.render(*b, 3, 5)
-        assert_bitwise(last, want_last, f"philox {scene} last frame (kernel option {kernel})")
-        assert_bitwise(acc, want, f"philox {scene} accum (kernel option {kernel})")
-    pcg, _ = run_gpu(tracer, (m.build_buffers()[0], spheres, tris, infos), 3, 2)
+@pytest.mark.parametrize("rays", [1, 3, 5, 16, 21, 64])
+def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene, rays):
+    """rt_params.rngMode = RT_RNG_PHILOX: Philox4x32-10, key (pixelIndex, Frame), counter (block, sample); a pixel's samples sit on
+    1 / 4 / 16 lanes of a wave (NumRaysPerPixel < 4 / < 16 / >= 16), each lane sums its sub-stream, the wave adds the sub-streams in
+    the estimator's fixed tree.  GPU == oracle twin, bit for bit, for every sub-stream shape and ragged last rounds (21 = 16 + 5)."""
+    m = rtx.scenes.config1(61, 43) if scene == "spheres" else rtx.scenes.mesh_test_scene(61, 43)
+    b = _philox(m.build_buffers(), rays)
+    want, want_last, cnt = oracle.render(*b, 3, 2)
+    acc, last = run_gpu(tracer, b, 3, 2, kernel=1)
+    st = tracer.stats()
+    assert st["lastKernel"] == 1 and st["lastSampleLanes"] == (16 if rays >= 16 else 4 if rays >= 4 else 1)
+    assert_bitwise(last, want_last, f"philox {scene} {rays} rays: last frame")
+    assert_bitwise(acc, want, f"philox {scene} {rays} rays: accum")
+    assert st["rays"] == cnt["rays"]
+
+
+def test_philox_mode_is_served_by_k_stream_whatever_kernel_is_asked_for(rtx, oracle, tracer):
+    """kernel = 0 / 2 / 3 / automatic in Philox mode all run k_stream's Philox instantiation (the only one with the estimator's
+    tree); zero rays per pixel draws nothing and goes to k_trace (0 / 0 = NaN in both modes, as in the oracle)."""
+    b = _philox(rtx.scenes.mesh_test_scene(48, 40).build_buffers(), 6)
+    want, want_last, _ = oracle.render(*b, 0, 3)
+    for kernel in (0, 2, 3, -1):
+        acc, last = run_gpu(tracer, b, 0, 3, kernel=kernel)
+        assert tracer.stats()["lastKernel"] == 1
+        assert_bitwise(acc, want, f"philox, kernel option {kernel}")
+    pcg, _ = run_gpu(tracer, (rtx.scenes.mesh_test_scene(48, 40).build_buffers()[0],) + b[1:], 0, 3)
     assert not np.array_equal(pcg, acc)
+    z = _philox(b, 0)
+    acc, last = run_gpu(tracer, z, 0, 1, kernel=-1)
+    want, _, _ = oracle.render(*z, 0, 1)
+    assert_bitwise(acc, want, "philox, zero rays per pixel")
 
 
-def test_philox_mode_with_frame_interleaved_items(rtx, oracle, tracer):
-    """The counter-based mode through k_stream's frame-interleaved items: 21 frames in one launch (one group of 16, one of 4, one
-    single frame), f16 and f32 nodes — the accumulated image and the ray count are the oracle twin's."""
-    params, spheres, tris, infos = rtx.scenes.mesh_test_scene(80, 56).build_buffers()
-    params = params.copy()
-    params["rngMode"] = 1
-    b = (params, spheres, tris, infos)
-    want, want_last, cnt = oracle.render(*b, 0, 21)
-    for compact in (1, 0):
-        tracer.set_option("compact_nodes", compact)
+@pytest.mark.parametrize("rays", [4, 64])
+def test_philox_mode_many_frames_in_one_launch_and_every_tuning_knob(rtx, oracle, tracer, rays):
+    """Items of several frames in one queue (21 frames, one launch), f16 and f32 nodes, groups of 1 / 5 / 40 items per fetch, a
+    two-entry LDS stack (spill path), SHADE thresholds 1 and 64: the accumulated image and the ray count are the oracle twin's."""
+    b = _philox(rtx.scenes.mesh_test_scene(80, 56).build_buffers(), rays, maxBounceCount=3)
+    nf = 21 if rays == 4 else 3
+    want, want_last, cnt = oracle.render(*b, 0, nf)
+    for compact, per_fetch, stack, thr in ((1, 16, 31, 48), (0, 1, 4, 1), (1, 5, 31, 64), (1, 40, 9, 24)):
+        tracer.set_option("compact_nodes", compact); tracer.set_option("tiles_per_fetch", per_fetch); tracer.set_option("stream_stack", stack)
         try:
-            acc, last = run_gpu(tracer, b, 0, 21, kernel=1)
+            acc, last = run_gpu(tracer, b, 0, nf, kernel=1, shade_threshold=thr)
             st = tracer.stats()
         finally:
-            tracer.set_option("compact_nodes", 1)
-        assert st["lastFramesPerLaunch"] == 21 and st["lastFramesInterleaved"] == 16
-        assert_bitwise(last, want_last, f"philox, 21 interleaved frames, compact_nodes={compact}: last frame")
-        assert_bitwise(acc, want, f"philox, 21 interleaved frames, compact_nodes={compact}: accum")
+            tracer.set_option("compact_nodes", 1); tracer.set_option("tiles_per_fetch", 16); tracer.set_option("stream_stack", 30)
+        what = f"philox, {nf} frames in one launch, {rays} rays, compact_nodes={compact}, {per_fetch} items per fetch, stack {stack}, threshold {thr}"
+        assert st["lastFramesPerLaunch"] == nf and st["lastSampleLanes"] == (16 if rays >= 16 else 4)
+        assert_bitwise(last, want_last, what + ": last frame")
+        assert_bitwise(acc, want, what + ": accum")
         assert st["rays"] == cnt["rays"]
+
+
+def test_philox_mode_rows_bands_and_depth_of_field(rtx, oracle, tracer):
+    """Global pixel indices key the stream: a row strip and an interleaved band set equal the same rows of the whole image; depth of
+    field on (the defocus draws of block 0 are used); counting build == fast build."""
+    m = rtx.scenes.mesh_test_scene(72, 64)
+    m.defocusStrength, m.divergeStrength = 60.0, 1.5
+    b = _philox(m.build_buffers(), 17)
+    full, _ = run_gpu(tracer, b, 2, 2, kernel=1)
+    want, _, cnt = oracle.render(*b, 2, 2)
+    assert_bitwise(full, want, "philox, depth of field")
+    strip, _ = run_gpu(tracer, b, 2, 2, kernel=1, rows=(19, 30))
+    assert_bitwise(strip, full[19:49], "philox, row strip")
+    tracer.set_bands(1, 3)
+    try:
+        tracer.set_params(b[0]); tracer.reset_accum(); tracer.render(2, 2)
+        got = tracer.read_accum()
+    finally:
+        tracer.set_rows(0, 64)
+    rows = [y for y in range(64) if (y // 8) % 3 == 1]
+    assert_bitwise(got, full[rows], "philox, bands 1 of 3")
+    tracer.set_params(b[0]); tracer.reset_accum(); tracer.render_counting(2, 2)
+    st = tracer.stats()
+    assert_bitwise(tracer.read_accum(), full, "philox, counting build")
+    assert st["rays"] == cnt["rays"] and st["hits"] == cnt["hits"]
 
 
 def test_multi_frame_launch_equals_frame_by_frame(rtx, oracle, tracer):

@@ -4,6 +4,7 @@ three by-value arguments out like the members of that struct.  This test reads t
 and checks the argument offsets and sizes in the metadata of every k_stream variant against the struct rule."""
 import os
 import re
+import shutil
 import struct
 
 import msgpack
@@ -53,7 +54,9 @@ def kernel_metadata(elf):
 def test_k_trace_kernarg_segment_is_laid_out_like_the_struct_view():
     """k_trace reads the per-tile part of its arguments through TraceKernArgs = {DeviceScene, FrameArgs}"""
     if not os.path.exists(LIB):
-        pytest.skip("library not built")
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.fail("librt_mi355x.so is not built although hipcc is present: run __graft_entry__.build()")
+        pytest.skip("library not built and no hipcc to build it with")
     blob = open(LIB, "rb").read()
     seen = 0
     for elf in code_objects(blob):
@@ -64,12 +67,14 @@ def test_k_trace_kernarg_segment_is_laid_out_like_the_struct_view():
             assert len(args) == 2, k[".name"]
             assert args[0][".offset"] == 0 and args[1][".offset"] == (args[0][".size"] + 7) & ~7, (k[".name"], args)
             seen += 1
-    assert seen >= 8
+    assert seen >= 7                                       # the flat twin + COUNT x H + COUNT x the six-wave sphere instantiation
 
 
 def test_k_stream_kernarg_segment_is_laid_out_like_the_struct_view():
     if not os.path.exists(LIB):
-        pytest.skip("library not built")
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.fail("librt_mi355x.so is not built although hipcc is present: run __graft_entry__.build()")
+        pytest.skip("library not built and no hipcc to build it with")
     blob = open(LIB, "rb").read()
     seen = 0
     for elf in code_objects(blob):

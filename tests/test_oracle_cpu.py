@@ -206,3 +206,107 @@ def test_philox_mode_is_a_different_stream_with_the_same_estimator(rtx, oracle):
     assert not np.array_equal(pcg, phx)
     lo = np.minimum(pcg[..., :3], 1).mean(), np.minimum(phx[..., :3], 1).mean()
     assert abs(lo[0] - lo[1]) < 0.05 * lo[0], lo
+
+
+def _philox4x32_10(ctr, key):
+    """Philox4x32-10 in plain Python integers (Salmon et al., SC'11) — independent of the oracle's C."""
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def test_philox_python_twin_matches_the_known_answers():
+    assert _philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert _philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+@pytest.mark.parametrize("rays", [1, 3, 5, 16, 37, 64])
+def test_philox_mode_addressing_and_estimator_tree_against_a_python_restatement(rtx, oracle, rays):
+    """The Philox mode's definition in a second, independent form (DESIGN.md "Counter-based mode"): on a scene with nothing to
+    hit, a sample's radiance is the environment light along its camera ray, which depends only on block 0 of
+    philox(key = (pixelIndex, Frame), counter = (0, sample, 0, 0)).  This restates frag :356-389 for that case in numpy float32
+    (transcendentals through the oracle's exported om_* functions), sums the samples in the defined tree — sub-stream s mod S added in
+    order, then pairs (k, k+1), (k, k+2), ... — and expects the oracle's image bit for bit: key / counter layout, draw order and
+    tree order are all pinned by it."""
+    f32 = np.float32
+    m = rtx.scenes.config1(7, 5)
+    m.spheres = []
+    m.numRaysPerPixel = rays
+    m.defocusStrength, m.divergeStrength = 2.5, 1.75
+    params, spheres, tris, infos = m.build_buffers()
+    params = params.copy(); params["rngMode"] = 1
+    frame = 11
+    got, _ = oracle.render_frame(params, spheres, tris, infos, frame)
+    L = oracle.lib
+    W, H = int(params["width"]), int(params["height"])
+    M = params["camLocalToWorld"].astype(f32)
+    vp = params["viewParams"].astype(f32)
+    right, up, pos = (M[0], M[4], M[8]), (M[1], M[5], M[9]), tuple(params["worldSpaceCameraPos"].astype(f32))
+    defocus, diverge = f32(params["defocusStrength"]), f32(params["divergeStrength"])
+    assert bool(params["environmentEnabled"])
+    ground, horizon, zenith = (params[k].astype(f32) for k in ("groundColour", "skyColourHorizon", "skyColourZenith"))
+    light_dir = params["worldSpaceLightPos0"].astype(f32)
+    sun_focus, sun_intensity = f32(params["sunFocus"]), f32(params["sunIntensity"])
+    S = 16 if rays >= 16 else 4 if rays >= 4 else 1
+    assert L.orc_philox_substreams(rays) == S
+
+    def sat(x):
+        return f32(min(max(x, f32(0)), f32(1)))
+
+    def smoothstep(e0, e1, x):
+        t = sat(f32(f32(x - e0) / f32(e1 - e0)))
+        return f32(f32(t * t) * f32(f32(3) - f32(f32(2) * t)))
+
+    def lerp(a, b, t):
+        return f32(a + f32(t * f32(b - a)))
+
+    def u01(r):
+        return f32(f32(np.uint32(r)) * f32(2.3283064365386963e-10))
+
+    def point_in_circle(ua, ub):
+        angle = f32(f32(ua * f32(2.0)) * f32(3.1415))
+        s = f32(np.sqrt(ub))
+        return f32(f32(L.om_cos(angle)) * s), f32(f32(L.om_sin(angle)) * s)
+
+    def env(d):
+        sky_t = f32(L.om_pow(smoothstep(f32(0), f32(0.4), d[1]), f32(0.35)))
+        g2s = smoothstep(f32(-0.01), f32(0), d[1])
+        sky = [lerp(horizon[c], zenith[c], sky_t) for c in range(3)]
+        dot = f32(f32(f32(d[0] * light_dir[0]) + f32(d[1] * light_dir[1])) + f32(d[2] * light_dir[2]))
+        sun = f32(f32(L.om_pow(f32(max(f32(0), dot)), sun_focus)) * sun_intensity)
+        sun_term = f32(sun * (f32(1) if g2s >= 1 else f32(0)))
+        return [f32(lerp(ground[c], sky[c], g2s) + sun_term) for c in range(3)]
+
+    want = np.zeros((H, W, 4), f32)
+    with np.errstate(all="ignore"):
+        for y in range(H):
+            for x in range(W):
+                uvx, uvy = f32(f32(f32(x) + f32(0.5)) / f32(W)), f32(f32(f32(y) + f32(0.5)) / f32(H))
+                lx, ly, lz = f32(f32(uvx - f32(0.5)) * vp[0]), f32(f32(uvy - f32(0.5)) * vp[1]), f32(f32(1) * vp[2])
+                focus = [f32(f32(f32(f32(M[4 * r] * lx) + f32(M[4 * r + 1] * ly)) + f32(M[4 * r + 2] * lz)) + f32(M[4 * r + 3] * f32(1))) for r in range(3)]
+                part = [[f32(0)] * 3 for _ in range(S)]
+                for s in range(rays):
+                    w = _philox4x32_10((0, s, 0, 0), (y * W + x, frame))
+                    jx, jy = point_in_circle(u01(w[0]), u01(w[1]))
+                    jx, jy = f32(f32(jx * defocus) / f32(W)), f32(f32(jy * defocus) / f32(W))
+                    origin = [f32(f32(pos[c] + f32(right[c] * jx)) + f32(up[c] * jy)) for c in range(3)]
+                    jx, jy = point_in_circle(u01(w[2]), u01(w[3]))
+                    jx, jy = f32(f32(jx * diverge) / f32(W)), f32(f32(jy * diverge) / f32(W))
+                    target = [f32(f32(focus[c] + f32(right[c] * jx)) + f32(up[c] * jy)) for c in range(3)]
+                    v = [f32(target[c] - origin[c]) for c in range(3)]
+                    ln = f32(np.sqrt(f32(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2]))))
+                    d = [f32(v[c] / ln) for c in range(3)]
+                    e = env(d)
+                    light = [f32(f32(0) + f32(e[c] * f32(1))) for c in range(3)]            # incomingLight += env * rayColour (:346)
+                    part[s % S] = [f32(part[s % S][c] + light[c]) for c in range(3)]
+                step = 1
+                while step < S:
+                    for k in range(0, S, 2 * step):
+                        part[k] = [f32(part[k][c] + part[k + step][c]) for c in range(3)]
+                    step *= 2
+                want[y, x] = [f32(part[0][c] / f32(rays)) for c in range(3)] + [f32(1)]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
