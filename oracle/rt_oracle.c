@@ -82,6 +82,22 @@ static inline float om_cos_poly(float r)
     return ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
            - 0.5f * z + 1.0f;
 }
+/* ORC_INTRINSICS_LIBM (a second build, oracle/Makefile target librt_oracle_libm.so — never the parity oracle): the transcendental
+ * intrinsics come from the host's libm instead of the frozen polynomial kernels.  Unity's shader compiler and the GPU driver evaluate
+ * sin / cos / log / pow with their own (unknown) approximations; rendering the reference's scenes with two different, both accurate,
+ * implementations shows how much of a converged image depends on that choice (tools/oracle_sensitivity.py). */
+#ifdef ORC_INTRINSICS_LIBM
+float om_sin(float x) { return sinf(x); }
+float om_cos(float x) { return cosf(x); }
+float om_log(float x) { return logf(x); }
+float om_exp2(float x) { return exp2f(x); }
+float om_pow(float x, float y) { return x == 0.0f ? 0.0f : powf(x, y); }
+#define om_sin om_sin_frozen_unused
+#define om_cos om_cos_frozen_unused
+#define om_log om_log_frozen_unused
+#define om_exp2 om_exp2_frozen_unused
+#define om_pow om_pow_frozen_unused
+#endif
 float om_sin(float x)
 {
     int n; float r = om_reduce(x, &n);
@@ -146,6 +162,13 @@ float om_pow(float x, float y)
     if (x == 0.0f) return 0.0f;                                                /* pow(0, y>0) = 0 */
     return om_exp2(y * om_log2(x));
 }
+#ifdef ORC_INTRINSICS_LIBM
+#undef om_sin
+#undef om_cos
+#undef om_log
+#undef om_exp2
+#undef om_pow
+#endif
 static inline float om_smoothstep(float e0, float e1, float x)
 {
     float t = om_saturate((x - e0) / (e1 - e0));

@@ -108,6 +108,7 @@ struct rt_ctx {
     int opt_shade_threshold = 48;
     int opt_tile_sync = 1;
     int opt_fetch_guide = 4;        // k_stream: groups of tiles_per_fetch items while more than this many groups per wave are left (then smaller)
+    int opt_fetch_guide_philox = 1; // ... the same in Philox mode
     int opt_tiles_per_fetch = 16;   // k_stream: items a wave reserves per fetch while the queue is long (guided: fewer near the end).  Fixed groups of
                                     // 2 / 4 / 8: 11.89 / 12.17 / 11.65 Grays/s (the tail grows); guided 4 / 8 / 12 / 16 / 24: 12.35 / 12.55 / 12.60 / 12.61 / 12.60.
                                     // 16 = the sub-tiles of one 8x8 tile in a 2x2x16 launch: groups stay tile-aligned (15.31 against 15.26 at 12)
@@ -735,7 +736,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
             // groups shrink towards the end of the launch (k_stream: guided self-scheduling): up to tiles_per_fetch items per fetch
             // while more than guide x (waves of the launch) x that many items are left
             A.tiles_per_fetch = std::max(1, std::min(rtk::kGroupMax, c->opt_tiles_per_fetch));
-            A.guide_div = std::max(1, grid * rtk::kWavesPerBlock * std::max(1, c->opt_fetch_guide));
+            // (Philox: the units of a group are small — a few samples — and handed out dynamically, so big groups balance by themselves and
+            // only the launch's last round of groups needs to shrink: a single 1080p frame 19.2 -> 17.5 ms with guide 1; PCG units are whole
+            // pixels and need the finer tail: 19.9 -> 47.9 ms with it)
+            A.guide_div = std::max(1, grid * rtk::kWavesPerBlock * (philox ? std::max(1, c->opt_fetch_guide_philox) : std::max(1, c->opt_fetch_guide)));
         }
         F.frame = first_frame + i;
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
@@ -1076,6 +1080,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "tile_lpt")) { c->opt_tile_lpt = value ? 1 : 0; c->tile_order_valid = false; }
     else if (!std::strcmp(name, "frame_batch")) { if (value < 0 || value > 1024) return fail(c, -2, "frame_batch must be in [0,1024]"); c->opt_frame_batch = value; }
     else if (!std::strcmp(name, "fetch_guide")) { if (value < 1 || value > 64) return fail(c, -2, "fetch_guide must be in [1,64]"); c->opt_fetch_guide = value; }
+    else if (!std::strcmp(name, "fetch_guide_philox")) { if (value < 1 || value > 64) return fail(c, -2, "fetch_guide_philox must be in [1,64]"); c->opt_fetch_guide_philox = value; }
     else if (!std::strcmp(name, "tiles_per_fetch")) { if (value < 1 || value > 64) return fail(c, -2, "tiles_per_fetch must be in [1,64]"); c->opt_tiles_per_fetch = value; }
     else if (!std::strcmp(name, "node_min")) { if (value < 1 || value > 64) return fail(c, -2, "node_min must be in [1,64]"); c->opt_node_min = value; }
     else if (!std::strcmp(name, "tile_sync")) c->opt_tile_sync = value ? 1 : 0;

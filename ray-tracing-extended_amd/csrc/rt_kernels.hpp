@@ -234,6 +234,17 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
         const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
         const float4 og = *reinterpret_cast<const float4*>(nb + (base + 112u));
         c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+#ifdef RT_PROBE_LOADS       // sensitivity probes (never in the product build; tools/build_variant.py): extra dwordx4 loads per node step ...
+        // (volatile C++ loads, not inline asm: the compiler's s_waitcnt bookkeeping does not see a load inside an asm, the registers it
+        // returns into are handed to other values at once and the late write-back corrupts them — the round-2 load probe had that fault)
+        for (int k_ = 0; k_ < RT_PROBE_LOADS; ++k_) (void)*reinterpret_cast<const volatile uint32_t*>(nb + (base + 124u));
+#endif
+#ifdef RT_PROBE_VALU        // ... extra full-rate VALU instructions (v_fma_f32) ...
+        { float pa_ = r.inv.x; for (int k_ = 0; k_ < RT_PROBE_VALU; ++k_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pa_)); }
+#endif
+#ifdef RT_PROBE_VALU_HALF   // ... or extra half-rate ones (v_max_f32)
+        { float pa_ = r.inv.x; for (int k_ = 0; k_ < RT_PROBE_VALU_HALF; ++k_) asm volatile("v_max_f32 %0, %0, %0" : "+v"(pa_)); }
+#endif
         // t = (origin + offset) * inv - o*inv = offset * inv + (origin * inv - o*inv): one f32 FMA per axis and node, then one
         // v_fma_mix_f32 (f16 offset x f32 + f32) per plane
         const float kx = __builtin_fmaf(og.x, r.inv.x, -r.oinv.x), ky = __builtin_fmaf(og.y, r.inv.y, -r.oinv.y), kz = __builtin_fmaf(og.z, r.inv.z, -r.oinv.z);
@@ -255,7 +266,7 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
     const uint4 ch = *reinterpret_cast<const uint4*>(nb + (base + 96u));
     c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
 #ifdef RT_PROBE_LOADS       // sensitivity probe (never in the product build): RT_PROBE_LOADS extra dwordx4 loads per node step
-    for (int k_ = 0; k_ < RT_PROBE_LOADS; ++k_) { float4 pv_; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pv_) : "v"(base + 112u), "s"(nb)); }
+    for (int k_ = 0; k_ < RT_PROBE_LOADS; ++k_) (void)*reinterpret_cast<const volatile uint32_t*>(nb + (base + 124u));
 #endif
 #ifdef RT_PROBE_VALU        // ... or RT_PROBE_VALU extra full-rate VALU instructions
     { float pa_ = r.inv.x; for (int k_ = 0; k_ < RT_PROBE_VALU; ++k_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pa_)); }
@@ -290,6 +301,12 @@ __device__ __forceinline__ void load_tri(const float4* __restrict__ tri_geo, uin
     g0 = *reinterpret_cast<const float4*>(tb + off);
     g1 = *reinterpret_cast<const float4*>(tb + (off + 16u));
     g2 = *reinterpret_cast<const float4*>(tb + (off + 32u));
+#ifdef RT_PROBE_LEAF_LOADS  // the same probes for a triangle test
+    for (int k_ = 0; k_ < RT_PROBE_LEAF_LOADS; ++k_) (void)*reinterpret_cast<const volatile uint32_t*>(tb + (off + 44u));
+#endif
+#ifdef RT_PROBE_LEAF_VALU
+    { float pa_ = g0.x; for (int k_ = 0; k_ < RT_PROBE_LEAF_VALU; ++k_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pa_)); }
+#endif
 }
 
 // A ray with a NaN in it, or a zero direction, can hit nothing (every RaySphere / RayTriangle comparison is false), but its

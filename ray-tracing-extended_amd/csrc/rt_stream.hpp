@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         ++bounce;
                         if (bounce > p.maxBounceCount) path_done = true;               // loop bound :305
                     } else {
-#ifndef RT_DIAG_IDLE
+#if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 3);
 #endif
                         light = light + environment_light(p, d) * rayColour;           // :346-347
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                 if (mode == kModeShade) {
                     if (need_ray) {
                         // ---- frag :364-382
-#ifndef RT_DIAG_IDLE
+#if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 4);
 #endif
                         Camera cam;
@@ -508,6 +508,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                     if ((int)cur >= 0) {
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
+#ifdef RT_DIAG_TOP       // diagnostic build only (tools/diag_primary.py top): node steps at the first RT_DIAG_TOP / 4 x RT_DIAG_TOP + 1 nodes (breadth-first order)
+                        if (COUNT && cur < (uint32_t)RT_DIAG_TOP) { cnt.phase_lanes[3]++; }
+                        if (COUNT && cur < 4u * RT_DIAG_TOP + 1u) { cnt.phase_lanes[4]++; }
+                        if (COUNT && ballot_(cur >= (uint32_t)RT_DIAG_TOP) == 0ull && (unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[3]++;
+                        if (COUNT && ballot_(cur >= 4u * RT_DIAG_TOP + 1u) == 0ull && (unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[4]++;
+#endif
+#ifdef RT_DIAG_PRIMARY   // diagnostic build only (tools/diag_primary.py): node steps / triangle tests of camera rays (bounce 0) in counters 3 / 4; execs = steps with any such lane
+                        if (COUNT && bounce == 0) { cnt.phase_lanes[3]++; if ((unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[3]++; }
+#endif
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
                         node_step<H>(H ? S.nodes_h : S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
@@ -542,6 +551,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         float dst, u, v;
                         if (COUNT) cnt.tris++;
                         phase_tick<COUNT>(cnt, 1);
+#ifdef RT_DIAG_PRIMARY
+                        if (COUNT && bounce == 0) { cnt.phase_lanes[4]++; if ((unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[4]++; }
+#endif
                         const bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
                                                       rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
                         if (hit && dst <= best.t) {
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0) atomicAdd(&F.counters[k], s);
+            if (lane == 0) atomicAdd(&fresh_kernargs<StreamKernArgs>().F.counters[k], s);     // (read here: not held across the persistent loop)
         }
     }
 }

@@ -23,10 +23,12 @@ def build_oracle():
 
 
 class Oracle:
-    def __init__(self):
+    def __init__(self, lib=None):
+        """lib: another build of the same source (oracle/Makefile `variants`: libm intrinsics, FMA contraction) for the sensitivity
+        study of tools/oracle_sensitivity.py; default = the parity oracle"""
         import rtx_pkg
         self.rtx = rtx_pkg.load()
-        self.lib = ctypes.CDLL(build_oracle())
+        self.lib = ctypes.CDLL(lib or build_oracle())
         L = self.lib
         L.orc_render_frame.restype = c_int
         L.orc_render_frame.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
