@@ -321,10 +321,23 @@ int rt_multi_read_accum      (rt_multi* m, float* rgba, size_t n_floats);
 /* rays and work counters summed over the contexts, kernel times = the slowest context's; gather_ms (may be NULL) = HIP-event
  * time of the last gather on the first device                                                                           */
 int rt_multi_get_stats       (rt_multi* m, rt_stats* out, double* gather_ms);
+/* How the handle is set up and what a scene change cost: the uploads go to the first context only, which builds the scene once;
+ * the other contexts receive the built scene device to device (over xGMI between GPUs) — bvhBuilds counts the builds of ALL
+ * contexts since rt_multi_create (one per scene change, whatever N).                                                          */
+typedef struct rt_multi_info {
+    int32_t numContexts;
+    int32_t bvhBuilds;                  /* BVH builds summed over the contexts since rt_multi_create                        */
+    double  lastSetupMs;                /* host wall time of the last scene change: build on the first context + fan-out   */
+    double  lastGatherMs;               /* HIP-event time of the last gather                                               */
+    int32_t device[16];                 /* HIP ordinal of context i (the first 16)                                         */
+    int32_t peerAccess[16];             /* 1: the first context's device and context i's read each other's memory directly */
+                                        /* (copies go GPU to GPU over xGMI), 0: the runtime stages them; [0] = 1            */
+} rt_multi_info;
+int rt_multi_get_info        (rt_multi* m, rt_multi_info* out);
 
 /* ABI self-description for binding generators / tests. */
 int rt_abi_version(void);
-int rt_sizeof(const char* struct_name);   /* "rt_material" | "rt_sphere" | "rt_triangle" | "rt_meshinfo" | "rt_params" | "rt_stats" | "rt_mesh_transform" | "rt_local_chunk" */
+int rt_sizeof(const char* struct_name);   /* "rt_material" | "rt_sphere" | "rt_triangle" | "rt_meshinfo" | "rt_params" | "rt_stats" | "rt_mesh_transform" | "rt_local_chunk" | "rt_multi_info" */
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ module `rtx_amd`.  Only what the hot path needs lives here:
     distributed.py  row-strip decomposition + frame-end gather
 """
 from . import _cabi, distributed, host, host_cpp_binding, imageio, scenes, unity_scene  # noqa: F401
-from ._cabi import (LOCAL_CHUNK, MATERIAL, MESH_TRANSFORM, MESHINFO, PARAMS, SPHERE, STATS, TRIANGLE, RT_INTERSECT_BRUTE,  # noqa: F401
+from ._cabi import (LOCAL_CHUNK, MATERIAL, MESH_TRANSFORM, MULTI_INFO, MESHINFO, PARAMS, SPHERE, STATS, TRIANGLE, RT_INTERSECT_BRUTE,  # noqa: F401
                     RT_INTERSECT_FLAT_CHUNKS, MultiTracer, RtError, Tracer, load_library)
 from .host import (Camera, EnvironmentSettings, Light, MaterialFlag, Mesh, MeshChunk, MeshSplitter, RayTracedMesh,  # noqa: F401
                    RayTracedSphere, RayTracingManager, RayTracingMaterial, Transform)

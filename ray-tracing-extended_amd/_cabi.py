@@ -45,6 +45,8 @@ STATS = np.dtype([
     ("bvhRebuilds", "<i4"), ("bvhRepads", "<i4"), ("lastSampleLanes", "<i4"), ("_reserved", "<i4"),
 ])
 MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])
+MULTI_INFO = np.dtype([("numContexts", "<i4"), ("bvhBuilds", "<i4"), ("lastSetupMs", "<f8"), ("lastGatherMs", "<f8"),
+                       ("device", "<i4", 16), ("peerAccess", "<i4", 16)])
 LOCAL_CHUNK = np.dtype([("firstTriangleIndex", "<u4"), ("numTriangles", "<u4"), ("meshIndex", "<u4"), ("_reserved", "<u4"),
                         ("material", MATERIAL)])
 assert MATERIAL.itemsize == 64 and SPHERE.itemsize == 80 and TRIANGLE.itemsize == 72 and MESHINFO.itemsize == 96
@@ -61,7 +63,7 @@ SYMBOLS = [
     "rt_read_bvh", "rt_write_accum",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_count", "rt_multi_context", "rt_multi_set_params",
     "rt_multi_upload_spheres", "rt_multi_upload_triangles", "rt_multi_upload_meshinfo", "rt_multi_set_option", "rt_multi_reset_accum",
-    "rt_multi_render", "rt_multi_read_accum", "rt_multi_get_stats",
+    "rt_multi_render", "rt_multi_read_accum", "rt_multi_get_stats", "rt_multi_get_info",
 ]
 
 _lib = None
@@ -127,6 +129,7 @@ def load_library() -> ctypes.CDLL:
     lib.rt_multi_render.argtypes = [c_void_p, c_int, c_int]
     lib.rt_multi_read_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t]
     lib.rt_multi_get_stats.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.rt_multi_get_info.argtypes = [c_void_p, c_void_p]
     for n in SYMBOLS:
         f = getattr(lib, n)
         if f.restype is None or n in ("rt_create", "rt_last_error", "rt_destroy", "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error",
@@ -135,7 +138,7 @@ def load_library() -> ctypes.CDLL:
         f.restype = c_int
     for name, dt in (("rt_material", MATERIAL), ("rt_sphere", SPHERE), ("rt_triangle", TRIANGLE),
                      ("rt_meshinfo", MESHINFO), ("rt_params", PARAMS), ("rt_stats", STATS),
-                     ("rt_mesh_transform", MESH_TRANSFORM), ("rt_local_chunk", LOCAL_CHUNK)):
+                     ("rt_mesh_transform", MESH_TRANSFORM), ("rt_local_chunk", LOCAL_CHUNK), ("rt_multi_info", MULTI_INFO)):
         got = lib.rt_sizeof(name.encode())
         if got != dt.itemsize:
             raise RtError(f"ABI mismatch: sizeof({name}) = {got} in the library, {dt.itemsize} in the binding")
@@ -361,3 +364,11 @@ class MultiTracer:
         d = {k: (s[k].item() if s[k].ndim == 0 else s[k].tolist()) for k in STATS.names}
         d["gatherMs"] = g.value
         return d
+
+    def info(self) -> dict:
+        """rt_multi_get_info: contexts, BVH builds summed over them, the last scene change's set-up time, peer access per context"""
+        s = np.zeros((), MULTI_INFO)
+        self._check(self._lib.rt_multi_get_info(self._m, s.ctypes.data_as(c_void_p)), "rt_multi_get_info")
+        n = int(s["numContexts"])
+        return {"numContexts": n, "bvhBuilds": int(s["bvhBuilds"]), "lastSetupMs": float(s["lastSetupMs"]), "lastGatherMs": float(s["lastGatherMs"]),
+                "device": s["device"][:min(n, 16)].tolist(), "peerAccess": s["peerAccess"][:min(n, 16)].tolist()}

@@ -18,8 +18,20 @@
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
 namespace rtk { const void* stream_kernel(bool counting, bool philox, bool compact); }   // rt_stream_kernels.hip
+// k_pool / k_wave: the two in-wave compaction schedulers of round 1 (measured 40 % / 28 % slower than k_stream, never selected).  They are
+// kept as tested alternatives but only in builds made with -DRT_EXPERIMENTAL_SCHEDULERS (RTX_EXPERIMENTAL=1 python -c "import
+// __graft_entry__ as g; g.build(True)"); the product library does not carry them and refuses kernel = 2 / 3.
+#ifdef RT_EXPERIMENTAL_SCHEDULERS
 #include "rt_pool.hpp"
 #include "rt_wave.hpp"
+#define RT_EXPERIMENTAL 1
+#else
+#define RT_EXPERIMENTAL 0
+namespace rtk { struct PoolArgs { unsigned int total_pixels; int trav_min_lanes, lds_stack_cap; unsigned int gstack_stride; uint32_t* gstack; };
+                struct WaveArgs { uint32_t* state; int refill_min, trav_min_lanes, node_min; unsigned int total_pixels; };
+                namespace pool { constexpr int kMaxSamples = 0; inline int wave_dwords(int) { return 0; } }
+                namespace wv { constexpr int kMaxSamples = 0, kMaxBounce = 0, kMaxFrames = 1; inline size_t wave_lds_bytes(int) { return 0; } inline size_t wave_state_dwords() { return 0; } } }
+#endif
 #include "rt_geom.hpp"
 #include "rt_bvh_gpu.hpp"
 
@@ -34,16 +46,17 @@ thread_local std::string g_create_error;
     } while (0)
 
 template <class T> struct DevBuf {
-    T* p = nullptr; size_t cap = 0;
+    T* p = nullptr; size_t cap = 0, used = 0;       // used: elements the last ensure() asked for (what clone_scene copies)
     hipError_t ensure(size_t n)
     {
+        used = n;
         if (n <= cap) return hipSuccess;
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
         if (e == hipSuccess) cap = std::max<size_t>(n, 1);
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; used = 0; }
 };
 
 } // namespace
@@ -63,6 +76,8 @@ struct rt_ctx {
     std::vector<rt_triangle> h_tris;
     std::vector<rt_meshinfo> h_mesh;
     bool scene_dirty = true;
+    size_t n_tris = 0, n_chunks = 0, n_spheres = 0;     // of the scene on the device (set by build_scene / build_scene_local / clone_scene)
+    float sphere_mag = 0.f;                             // largest |coordinate| of a sphere surface point of that scene
     // on-device geometry pipeline (rt_upload_local_meshes / rt_set_mesh_transforms)
     bool geom_local = false, xf_dirty = false;
     std::vector<rt_triangle>       h_local_tris;
@@ -350,6 +365,7 @@ int build_scene(rt_ctx* c)
 
     c->stats.numSpheres = (int)ns; c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->n_nodes; c->stats.bvhMaxStack = c->bvh.maxStack; c->stats.bvhInternalArea = c->area_at_build;
+    c->n_spheres = ns; c->n_tris = nt; c->n_chunks = nm; c->sphere_mag = sphere_magnitude(c);
     c->scene_dirty = false; c->tile_order_valid = false;
     return 0;
 }
@@ -515,7 +531,42 @@ int build_scene_local(rt_ctx* c)
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->n_nodes; c->stats.bvhMaxStack = c->bvh.maxStack; c->stats.bvhInternalArea = c->area_at_build;
+    c->n_spheres = c->h_spheres.size(); c->n_tris = nt; c->n_chunks = nm; c->sphere_mag = sphere_magnitude(c);
     c->scene_dirty = false; c->xf_dirty = false; c->tile_order_valid = false;
+    return 0;
+}
+
+// Give `dst` the scene `src` has built (world-space uploads): every device buffer is copied device to device — over xGMI when the
+// contexts sit on different GPUs — and the host-side description of the tree comes along; dst builds nothing and holds no host copy of
+// the triangles.  rt_multi uses it so that N contexts cost one BVH build and one host -> device upload per scene change.
+template <class T> int clone_buf(rt_ctx* dst, DevBuf<T>& d, const rt_ctx* src, const DevBuf<T>& s)
+{
+    RT_HIP(dst, d.ensure(s.used));
+    if (!s.used) return 0;
+    if (dst->device == src->device) RT_HIP(dst, hipMemcpyAsync(d.p, s.p, s.used * sizeof(T), hipMemcpyDeviceToDevice, dst->stream));
+    else RT_HIP(dst, hipMemcpyPeerAsync(d.p, dst->device, s.p, src->device, s.used * sizeof(T), dst->stream));
+    return 0;
+}
+int clone_scene(rt_ctx* dst, rt_ctx* src)
+{
+    if (src->scene_dirty || src->geom_local) return fail(dst, -2, "clone_scene: the source context has no built world-space scene");
+    RT_HIP(dst, hipSetDevice(src->device));
+    RT_HIP(dst, hipStreamSynchronize(src->stream));
+    RT_HIP(dst, hipSetDevice(dst->device));
+#define RT_CLONE(B) { int r_ = clone_buf(dst, dst->B, src, src->B); if (r_) return r_; }
+    RT_CLONE(d_sph_geom) RT_CLONE(d_sph_mat) RT_CLONE(d_nodes) RT_CLONE(d_nodes_h) RT_CLONE(d_tri_geo) RT_CLONE(d_tri_nrm)
+    RT_CLONE(d_chunk_mat) RT_CLONE(d_chunk_box) RT_CLONE(d_raw_tris) RT_CLONE(d_raw_range) RT_CLONE(d_order)
+#undef RT_CLONE
+    RT_HIP(dst, hipStreamSynchronize(dst->stream));
+    dst->h_spheres.clear(); dst->h_tris.clear(); dst->h_mesh.clear(); dst->geom_local = false;
+    dst->bvh.nodes.clear(); dst->bvh.order.clear();
+    dst->bvh.levelStart = src->bvh.levelStart; dst->bvh.maxStack = src->bvh.maxStack; dst->bvh.depth = src->bvh.depth; dst->bvh.magnitude = src->bvh.magnitude;
+    dst->n_nodes = src->n_nodes; dst->area_at_build = src->area_at_build;
+    dst->n_spheres = src->n_spheres; dst->n_tris = src->n_tris; dst->n_chunks = src->n_chunks; dst->sphere_mag = src->sphere_mag;
+    dst->stats.numSpheres = src->stats.numSpheres; dst->stats.numTriangles = src->stats.numTriangles; dst->stats.numMeshChunks = src->stats.numMeshChunks;
+    dst->stats.numBvhNodes = src->stats.numBvhNodes; dst->stats.bvhMaxStack = src->stats.bvhMaxStack; dst->stats.bvhInternalArea = src->stats.bvhInternalArea;
+    dst->stats.bvhBuiltOnDevice = src->stats.bvhBuiltOnDevice; dst->stats.lastBvhBuildMs = 0.0;
+    dst->scene_dirty = false; dst->tile_order_valid = false; dst->auto_choice = -1;
     return 0;
 }
 
@@ -568,7 +619,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     } else {
         if (c->scene_dirty) { int r = build_scene(c); if (r) return r; }
         else {
-            const float om = std::max(camera_magnitude(c->params), sphere_magnitude(c));
+            const float om = std::max(camera_magnitude(c->params), c->sphere_mag);
             if (om > c->bvh.magnitude) { int r = repad_boxes(c, 2.0f * om); if (r) return r; }     // widen the box padding, keep the tree
         }
     }
@@ -579,12 +630,12 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     S.sph_geom = c->d_sph_geom.p; S.sph_mat = c->d_sph_mat.p; S.nodes = c->d_nodes.p; S.nodes_h = c->d_nodes_h.p;
     S.tri_geo = c->d_tri_geo.p; S.tri_nrm = c->d_tri_nrm.p; S.chunk_mat = c->d_chunk_mat.p; S.chunk_box = c->d_chunk_box.p;
     S.raw_tris = c->d_raw_tris.p; S.raw_chunk_range = c->d_raw_range.p;
-    S.ns = (int)c->h_spheres.size(); S.nn = (int)c->n_nodes;
+    S.ns = (int)c->n_spheres; S.nn = (int)c->n_nodes;
     // the kernels address nodes and BVH-order triangles with 32-bit byte offsets (128 B and 48 B records)
-    if (c->n_nodes >= ((size_t)1 << 25) || (c->geom_local ? c->h_local_tris.size() : c->h_tris.size()) >= ((size_t)1 << 32) / 48)
+    if (c->n_nodes >= ((size_t)1 << 25) || c->n_tris >= ((size_t)1 << 32) / 48)
         return fail(c, -7, "scene too large for 32-bit record offsets (%zu BVH nodes)", c->n_nodes);
-    S.nt = c->geom_local ? (int)c->h_local_tris.size() : (int)c->h_tris.size();
-    S.nm = c->geom_local ? (int)c->h_lchunks.size() : (int)c->h_mesh.size();
+    S.nt = (int)c->n_tris;
+    S.nm = (int)c->n_chunks;
 
     rtk::FrameArgs F{};
     F.p = c->params;
@@ -604,9 +655,9 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (philox && (c->target_w > 65535 || c->target_rows > 65535)) return fail(c, -7, "the Philox mode addresses at most 65535 x 65535 pixels per context");
     const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1        // PCG or Philox instantiation
                         && c->target_w <= 65535 && c->target_rows <= 65535;                          // (16-bit pixel coordinates in k_stream's item tables)
-    const bool pooled = !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
+    const bool pooled = RT_EXPERIMENTAL && !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                         && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
-    const bool waved = !philox && kernel == 3 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
+    const bool waved = RT_EXPERIMENTAL && !philox && kernel == 3 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
                        && c->params.numRaysPerPixel <= rtk::wv::kMaxSamples && c->params.maxBounceCount <= rtk::wv::kMaxBounce
                        && c->target_w <= 65535 && c->target_rows <= 65535;
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream || waved ? 3 : 0);    // the branch-free push writes up to 3 slots past the top
@@ -631,8 +682,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     const bool counting = var == Variant::Counting;
     const bool compact = c->opt_compact_nodes != 0;            // k_trace / k_stream only; k_pool, k_wave and the flat twin read the f32 nodes
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
+#if RT_EXPERIMENTAL
                    : pooled ? (counting ? (const void*)rtk::k_pool<true> : (const void*)rtk::k_pool<false>)
                    : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
+#endif
                    : stream ? rtk::stream_kernel(counting, philox, compact)       // instantiated in rt_stream_kernels.hip
                    : c->n_nodes == 0      // spheres only: the instantiation compiled for six waves per SIMD
                             ? dispatch3(counting, false, false, [](auto C, auto, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, false, 6>; })
@@ -906,6 +959,7 @@ int rt_sizeof(const char* name)
     if (!std::strcmp(name, "rt_stats"))    return (int)sizeof(rt_stats);
     if (!std::strcmp(name, "rt_mesh_transform")) return (int)sizeof(rt_mesh_transform);
     if (!std::strcmp(name, "rt_local_chunk")) return (int)sizeof(rt_local_chunk);
+    if (!std::strcmp(name, "rt_multi_info")) return (int)sizeof(rt_multi_info);
     return -1;
 }
 
@@ -1063,7 +1117,11 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
 {
     if (!c) return -1;
     if (!name) return fail(c, -2, "null option name");
-    if (!std::strcmp(name, "kernel")) { if (value < -1 || value > 3) return fail(c, -2, "kernel must be -1 (auto), 0, 1, 2 or 3"); c->opt_kernel = value; }
+    if (!std::strcmp(name, "kernel")) {
+        if (value < -1 || value > 3) return fail(c, -2, "kernel must be -1 (auto), 0, 1, 2 or 3");
+        if (!RT_EXPERIMENTAL && value >= 2) return fail(c, -8, "kernel %d (k_pool / k_wave) is not compiled into this build of the library (RT_EXPERIMENTAL_SCHEDULERS)", value);
+        c->opt_kernel = value;
+    }
     else if (!std::strcmp(name, "pool_stack")) { if (value < 1 || value > 64) return fail(c, -2, "pool_stack must be in [1,64]"); c->opt_pool_stack = value; }
     else if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) return fail(c, -2, "refill_min must be in [1,64]"); c->opt_refill_min = value; }
     else if (!std::strcmp(name, "wave_node_min")) { if (value < 1 || value > 64) return fail(c, -2, "wave_node_min must be in [1,64]"); c->opt_wave_node_min = value; }
@@ -1207,7 +1265,9 @@ struct rt_multi {
     bool have_params = false;
     DevBuf<float4> d_image, d_staging;          // on the first context's device: the assembled image, the incoming strips
     int max_rows = 0;
-    double lastGatherMs = 0;
+    double lastGatherMs = 0, lastSetupMs = 0;
+    bool scene_dirty = true;                    // the first context holds an upload the others have not received yet
+    std::vector<int> peer;                      // per context: 1 = the first context's device reads its memory directly (peer access on), 0 = staged by the runtime
 };
 
 namespace {
@@ -1219,6 +1279,13 @@ int mfail(rt_multi* m, int code, const char* fmt, ...)
     if (m) m->err = buf; else g_create_error = buf;
     return code;
 }
+
+// HIP calls of the gather / distribution phases: the failure goes to the rt_multi's own error string (rt_multi_last_error)
+#define M_HIP(m, expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return mfail(m, -100, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
 
 template <class Fn> int for_each_ctx(rt_multi* m, const char* what, Fn f)
 {
@@ -1255,14 +1322,22 @@ rt_multi* rt_multi_create(const int* devices, int n_devices)
         if (!c) { const std::string e = g_create_error; rt_multi_destroy(m); g_create_error = e; return nullptr; }
         m->ctx.push_back(c);
     }
-    // direct peer copies into the first device where the hardware allows it (errors here only mean a slower copy path)
-    (void)hipSetDevice(m->ctx[0]->device);
+    // direct peer copies between the first device and the others where the hardware allows it; a refusal only means that the runtime
+    // stages the copy (rt_multi_get_info reports which it is, per context)
+    m->peer.assign(n_devices, 1);
     for (int i = 1; i < n_devices; ++i)
         if (m->ctx[i]->device != m->ctx[0]->device) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, m->ctx[0]->device, m->ctx[i]->device) == hipSuccess && can)
-                (void)hipDeviceEnablePeerAccess(m->ctx[i]->device, 0);
+            int ok = 1;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int a = dir ? m->ctx[i]->device : m->ctx[0]->device, b = dir ? m->ctx[0]->device : m->ctx[i]->device;
+                int can = 0;
+                (void)hipSetDevice(a);
+                if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { ok = 0; continue; }
+                const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = 0;
+            }
             (void)hipGetLastError();
+            m->peer[i] = ok;
         }
     return m;
 }
@@ -1292,10 +1367,24 @@ int rt_multi_set_params(rt_multi* m, const rt_params* p)
     m->width = p->width; m->height = p->height; m->have_params = true;
     return 0;
 }
-int rt_multi_upload_spheres(rt_multi* m, const rt_sphere* s, int n) { return m ? for_each_ctx(m, "rt_upload_spheres", [&](rt_ctx* c) { return rt_upload_spheres(c, s, n); }) : -1; }
-int rt_multi_upload_triangles(rt_multi* m, const rt_triangle* t, int n) { return m ? for_each_ctx(m, "rt_upload_triangles", [&](rt_ctx* c) { return rt_upload_triangles(c, t, n); }) : -1; }
-int rt_multi_upload_meshinfo(rt_multi* m, const rt_meshinfo* mi, int n) { return m ? for_each_ctx(m, "rt_upload_meshinfo", [&](rt_ctx* c) { return rt_upload_meshinfo(c, mi, n); }) : -1; }
-int rt_multi_set_option(rt_multi* m, const char* name, int value) { return m ? for_each_ctx(m, "rt_set_option", [&](rt_ctx* c) { return rt_set_option(c, name, value); }) : -1; }
+// The three buffers go to the FIRST context only: it builds the scene once (re-layout + BVH) at the next rt_multi_render and the other
+// contexts receive the built scene device to device (clone_scene) — one build and one host -> device upload per scene change, whatever N.
+static int multi_upload(rt_multi* m, int r, const char* what)
+{
+    if (r) return mfail(m, r, "%s on context 0: %s", what, rt_last_error(m->ctx[0]));
+    m->scene_dirty = true;
+    return 0;
+}
+int rt_multi_upload_spheres(rt_multi* m, const rt_sphere* s, int n) { return m ? multi_upload(m, rt_upload_spheres(m->ctx[0], s, n), "rt_upload_spheres") : -1; }
+int rt_multi_upload_triangles(rt_multi* m, const rt_triangle* t, int n) { return m ? multi_upload(m, rt_upload_triangles(m->ctx[0], t, n), "rt_upload_triangles") : -1; }
+int rt_multi_upload_meshinfo(rt_multi* m, const rt_meshinfo* mi, int n) { return m ? multi_upload(m, rt_upload_meshinfo(m->ctx[0], mi, n), "rt_upload_meshinfo") : -1; }
+int rt_multi_set_option(rt_multi* m, const char* name, int value)
+{
+    if (!m) return -1;
+    const int r = for_each_ctx(m, "rt_set_option", [&](rt_ctx* c) { return rt_set_option(c, name, value); });
+    if (!r && m->ctx[0]->scene_dirty) m->scene_dirty = true;        // (a builder option: the first context rebuilds, the others receive the new tree)
+    return r;
+}
 int rt_multi_reset_accum(rt_multi* m) { return m ? for_each_ctx(m, "rt_reset_accum", [&](rt_ctx* c) { return rt_reset_accum(c); }) : -1; }
 
 int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
@@ -1303,6 +1392,23 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
     if (!m) return -1;
     if (!m->have_params) return mfail(m, -2, "rt_multi_set_params has not been called");
     const int N = (int)m->ctx.size();
+    bool stale = m->scene_dirty;
+    for (rt_ctx* c : m->ctx) stale = stale || c->scene_dirty;       // (a builder option set through rt_multi_context(i), a context never filled)
+    if (stale) {
+        // ---- scene change: the first context builds (one BVH build, one host -> device upload), the others receive the result
+        const double t0 = now_ms();
+        rt_ctx* root = m->ctx[0];
+        { int r = launch_frames(root, first_frame, 0, Variant::Fast); if (r) return mfail(m, r, "scene build on context 0: %s", rt_last_error(root)); }
+        std::vector<int> rcs(N, 0);
+        {
+            std::vector<std::thread> th;
+            for (int i = 1; i < N; ++i) th.emplace_back([&, i]() { rcs[i] = clone_scene(m->ctx[i], root); });
+            for (std::thread& t : th) t.join();
+        }
+        for (int i = 1; i < N; ++i) if (rcs[i]) return mfail(m, rcs[i], "scene transfer to context %d: %s", i, rt_last_error(m->ctx[i]));
+        m->scene_dirty = false;
+        m->lastSetupMs = now_ms() - t0;
+    }
     // every device renders its bands for all frames, concurrently: one host thread per context (a context is single-threaded,
     // the contexts are independent)
     std::vector<int> rc(N, 0);
@@ -1317,18 +1423,18 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
     rt_ctx* root = m->ctx[0];
     const int W = m->width, H = m->height;
     if ((size_t)W * H == 0) return 0;
-    RT_HIP(root, hipSetDevice(root->device));
+    M_HIP(m, hipSetDevice(root->device));
     int max_rows = 0;
     for (rt_ctx* c : m->ctx) max_rows = std::max(max_rows, c->target_rows);
-    RT_HIP(root, m->d_image.ensure((size_t)W * H));
-    RT_HIP(root, m->d_staging.ensure((size_t)W * max_rows * (size_t)std::max(1, N - 1)));
-    RT_HIP(root, hipEventRecord(root->evg0, root->stream));
+    M_HIP(m, m->d_image.ensure((size_t)W * H));
+    M_HIP(m, m->d_staging.ensure((size_t)W * max_rows * (size_t)std::max(1, N - 1)));
+    M_HIP(m, hipEventRecord(root->evg0, root->stream));
     for (int i = 1; i < N; ++i) {
         rt_ctx* c = m->ctx[i];
         if (c->target_pixels == 0) continue;
         float4* dst = m->d_staging.p + (size_t)(i - 1) * W * max_rows;
-        if (c->device == root->device) RT_HIP(root, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, root->stream));
-        else RT_HIP(root, hipMemcpyPeerAsync(dst, root->device, c->d_accum.p, c->device, c->target_pixels * sizeof(float4), root->stream));
+        if (c->device == root->device) M_HIP(m, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, root->stream));
+        else M_HIP(m, hipMemcpyPeerAsync(dst, root->device, c->d_accum.p, c->device, c->target_pixels * sizeof(float4), root->stream));
     }
     for (int i = 0; i < N; ++i) {
         rt_ctx* c = m->ctx[i];
@@ -1337,11 +1443,11 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
         const int bands = (c->target_rows + 7) / 8;
         hipLaunchKernelGGL(k_scatter_bands, dim3(std::max(1, std::min(64, (W * 8 + 255) / 256)), bands), dim3(256), 0, root->stream, src, m->d_image.p, W, H, i, N);
     }
-    RT_HIP(root, hipGetLastError());
-    RT_HIP(root, hipEventRecord(root->evg1, root->stream));
-    RT_HIP(root, hipStreamSynchronize(root->stream));
+    M_HIP(m, hipGetLastError());
+    M_HIP(m, hipEventRecord(root->evg1, root->stream));
+    M_HIP(m, hipStreamSynchronize(root->stream));
     float ms = 0.f;
-    RT_HIP(root, hipEventElapsedTime(&ms, root->evg0, root->evg1));
+    M_HIP(m, hipEventElapsedTime(&ms, root->evg0, root->evg1));
     m->lastGatherMs = ms;
     return 0;
 }
@@ -1354,8 +1460,8 @@ int rt_multi_read_accum(rt_multi* m, float* rgba, size_t n_floats)
     if (!n_floats) return 0;
     if (!m->d_image.p) return mfail(m, -2, "nothing rendered yet");
     rt_ctx* root = m->ctx[0];
-    RT_HIP(root, hipSetDevice(root->device));
-    RT_HIP(root, hipMemcpy(rgba, m->d_image.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    M_HIP(m, hipSetDevice(root->device));
+    M_HIP(m, hipMemcpy(rgba, m->d_image.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1372,6 +1478,18 @@ int rt_multi_get_stats(rt_multi* m, rt_stats* out, double* gather_ms)
     }
     *out = sum;
     if (gather_ms) *gather_ms = m->lastGatherMs;
+    return 0;
+}
+
+int rt_multi_get_info(rt_multi* m, rt_multi_info* out)
+{
+    if (!m) return -1;
+    if (!out) return mfail(m, -2, "null info");
+    std::memset(out, 0, sizeof *out);
+    out->numContexts = (int32_t)m->ctx.size();
+    for (rt_ctx* c : m->ctx) out->bvhBuilds += c->stats.bvhBuilds;
+    out->lastSetupMs = m->lastSetupMs; out->lastGatherMs = m->lastGatherMs;
+    for (size_t i = 0; i < m->ctx.size() && i < 16; ++i) { out->device[i] = m->ctx[i]->device; out->peerAccess[i] = m->peer[i]; }
     return 0;
 }
 

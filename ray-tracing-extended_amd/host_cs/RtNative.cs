@@ -1,7 +1,7 @@
 // RtNative.cs — P/Invoke binding of include/rt.h (librt_mi355x.so), complete: every exported entry point and every struct.
 //
-// Drop into Assets/Scripts/Native/ of the reference project together with RayTracingManager.cs from this directory, which
-// replaces Assets/Scripts/RayTracingManager.cs (same class name and serialised fields, so the .unity scenes load unchanged).
+// Drop into Assets/Scripts/Native/ of the reference project together with RtBackend.cs, and apply RayTracingManager.cs.ed (the line
+// edits that make the reference's own RayTracingManager call RtBackend instead of its material blits; INTEGRATION.md).
 // The structs below are plain sequential layouts with primitive fields and fixed buffers only (no UnityEngine types), so that
 // tests/test_csharp_binding_cpu.py can parse them and check every field offset against the C headers' layouts
 // (this image has no C# toolchain: the file is shipped as source and verified structurally).
@@ -131,6 +131,17 @@ namespace RtMi355x
         public int _reserved;
     }
 
+    [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct RtMultiInfo                // rt_multi_info
+    {
+        public int numContexts;
+        public int bvhBuilds;
+        public double lastSetupMs;
+        public double lastGatherMs;
+        public fixed int device[16];
+        public fixed int peerAccess[16];
+    }
+
     public enum RngMode { Pcg = 0, Philox = 1 }
     public enum IntersectMode { FlatChunks = 0, Brute = 1 }
 
@@ -186,6 +197,7 @@ namespace RtMi355x
         [DllImport(Lib)] public static extern int rt_multi_render(IntPtr multi, int firstFrame, int nFrames);
         [DllImport(Lib)] public static extern int rt_multi_read_accum(IntPtr multi, IntPtr rgba, UIntPtr nFloats);
         [DllImport(Lib)] public static extern int rt_multi_get_stats(IntPtr multi, out RtStats stats, out double gatherMs);
+        [DllImport(Lib)] public static extern int rt_multi_get_info(IntPtr multi, out RtMultiInfo info);
 
         // ---- helpers --------------------------------------------------------------------------------------------------
         public static string LastError(IntPtr ctx) { return Marshal.PtrToStringAnsi(rt_last_error(ctx)) ?? ""; }
@@ -226,6 +238,7 @@ namespace RtMi355x
             Same("rt_local_chunk", Marshal.SizeOf<RtLocalChunk>());
             Same("rt_params", Marshal.SizeOf<RtParams>());
             Same("rt_stats", Marshal.SizeOf<RtStats>());
+            Same("rt_multi_info", Marshal.SizeOf<RtMultiInfo>());
         }
     }
 }

@@ -4,6 +4,9 @@ same fields in the same order at the same offsets (C# LayoutKind.Sequential = na
 size rt_sizeof() reports."""
 import os
 import re
+import sys
+
+import pytest
 
 import numpy as np
 
@@ -63,7 +66,8 @@ def test_csharp_struct_layouts_match_the_c_abi(rtx):
     lib = rtx.load_library()
     pairs = {"RtMaterial": ("rt_material", rtx.MATERIAL), "RtSphere": ("rt_sphere", rtx.SPHERE), "RtTriangle": ("rt_triangle", rtx.TRIANGLE),
              "RtMeshInfo": ("rt_meshinfo", rtx.MESHINFO), "RtMeshTransform": ("rt_mesh_transform", rtx.MESH_TRANSFORM),
-             "RtLocalChunk": ("rt_local_chunk", rtx.LOCAL_CHUNK), "RtParams": ("rt_params", rtx.PARAMS), "RtStats": ("rt_stats", rtx.STATS)}
+             "RtLocalChunk": ("rt_local_chunk", rtx.LOCAL_CHUNK), "RtParams": ("rt_params", rtx.PARAMS), "RtStats": ("rt_stats", rtx.STATS),
+             "RtMultiInfo": ("rt_multi_info", rtx.MULTI_INFO)}
     assert set(structs) == set(pairs)
     for cs_name, (c_name, dt) in pairs.items():
         rows, size, _ = _layout(structs, cs_name)
@@ -78,7 +82,8 @@ def test_c_header_field_order_matches_the_binding(rtx):
     """include/rt.h itself: field names of each typedef struct, in order, equal the numpy layouts the tests and the C# file use."""
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt.h")).read(), flags=re.S)
     dts = {"rt_material": rtx.MATERIAL, "rt_sphere": rtx.SPHERE, "rt_triangle": rtx.TRIANGLE, "rt_meshinfo": rtx.MESHINFO,
-           "rt_mesh_transform": rtx.MESH_TRANSFORM, "rt_local_chunk": rtx.LOCAL_CHUNK, "rt_params": rtx.PARAMS, "rt_stats": rtx.STATS}
+           "rt_mesh_transform": rtx.MESH_TRANSFORM, "rt_local_chunk": rtx.LOCAL_CHUNK, "rt_params": rtx.PARAMS, "rt_stats": rtx.STATS,
+           "rt_multi_info": rtx.MULTI_INFO}
     for name, dt in dts.items():
         body = re.search(r"typedef struct " + name + r"\s*\{(.*?)\}\s*" + name + ";", header, re.S).group(1)
         names = []
@@ -91,16 +96,44 @@ def test_c_header_field_order_matches_the_binding(rtx):
         assert names == list(dt.names), (name, names, dt.names)
 
 
-def test_manager_source_keeps_the_references_serialised_surface():
-    """host_cs/RayTracingManager.cs: the class and the serialised field names the .unity scenes carry (Chess.unity:30174-30191),
-    and every native call it makes exists in RtNative.cs."""
-    text = open(os.path.join(CS, "RayTracingManager.cs")).read()
-    assert re.search(r"public class RayTracingManager\s*:\s*MonoBehaviour", text) and "public const int TriangleLimit = 1500;" in text
-    for field in ("maxBounceCount", "numRaysPerPixel", "defocusStrength", "divergeStrength", "focusDistance", "environmentSettings",
-                  "useShaderInSceneView", "rayTracingShader", "accumulateShader", "numRenderedFrames", "numMeshChunks", "numTriangles"):
-        assert re.search(r"\[SerializeField[^\]]*\]\s*\w+\s+" + field + r"\b", text), field
+def test_backend_class_only_calls_what_the_binding_declares():
+    """host_cs/RtBackend.cs (the other side of the reference's material-property boundary): every native call exists in RtNative.cs."""
+    text = open(os.path.join(CS, "RtBackend.cs")).read()
     native = open(os.path.join(CS, "RtNative.cs")).read()
     available = set(re.findall(r"static\s+(?:extern\s+)?[\w<>\[\]]+\s+(\w+)\s*[<(]", native))
     used = set(re.findall(r"RtNative\.(\w+)", text)) - {"cs"}            # ("RtNative.cs" in comments)
-    assert used <= available | {"UploadCall"}, used - available
-    assert "..." not in text and "// ..." not in text
+    assert used and used <= available | {"UploadCall"}, used - available
+    assert "..." not in text
+
+
+def test_manager_patch_applies_to_the_reference_and_keeps_its_serialised_surface():
+    """host_cs/RayTracingManager.cs.ed: the line edits a maintainer applies to the reference's own RayTracingManager.cs
+    (`patch -e`, or tools/apply_ed.py).  An ed script carries line numbers and the new lines only — none of the reference's text.
+    Applied to the reference file (read here, on the build machine only), the result keeps the class, every serialised field the .unity
+    scenes carry (Chess.unity:30174-30191) and the scene-building code, calls only methods RtBackend has, and no longer touches a
+    Material, a ComputeBuffer or ShaderHelper."""
+    ref = "/root/reference/Assets/Scripts/RayTracingManager.cs"
+    if not os.path.exists(ref):
+        pytest.skip("the reference project is not on this machine")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import apply_ed
+    script = open(os.path.join(CS, "RayTracingManager.cs.ed")).read().splitlines(True)
+    text = "".join(apply_ed.apply_ed(open(ref, newline="").read().replace("\r\n", "\n").splitlines(True), script))
+    assert re.search(r"public class RayTracingManager\s*:\s*MonoBehaviour", text) and "public const int TriangleLimit = 1500;" in text
+    for field in ("maxBounceCount", "numRaysPerPixel", "defocusStrength", "divergeStrength", "focusDistance", "environmentSettings",
+                  "useShaderInSceneView", "rayTracingShader", "accumulateShader", "numRenderedFrames", "numMeshChunks", "numTriangles",
+                  "devices", "literalChunkCull", "philox"):
+        assert re.search(r"\[SerializeField[^\]]*\]\s*[\w\[\]]+\s+" + field + r"\b", text), field
+    assert text.count("{") == text.count("}")
+    for gone in ("rayTracingMaterial", "accumulateMaterial", "ComputeBuffer", "ShaderHelper", "RenderTexture.GetTemporary"):
+        assert gone not in text, gone
+    for kept in ("FindObjectsOfType<RayTracedMesh>()", "FindObjectsOfType<RayTracedSphere>()", "GetSubMeshes()", "OnValidate"):
+        assert kept in text, kept
+    backend = open(os.path.join(CS, "RtBackend.cs")).read()
+    methods = set(re.findall(r"public\s+(?:unsafe\s+)?[\w<>\[\]]+\s+(\w+)\s*[<(]", backend))
+    called = set(re.findall(r"backend\??\.(\w+)\(", text))
+    assert called and called <= methods, called - methods
+    # the script itself holds no line of the reference
+    ref_lines = {l.strip() for l in open(ref).read().splitlines() if len(l.strip()) > 12}
+    new_lines = [l.strip() for l in script if not re.fullmatch(r"\d+(,\d+)?[acd]\n|\.\n", l)]
+    assert not [l for l in new_lines if l in ref_lines]

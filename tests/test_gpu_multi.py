@@ -39,6 +39,39 @@ def test_n_contexts_behind_rt_multi_equal_the_undivided_image(rtx, oracle, trace
     assert st["gatherMs"] >= 0.0
 
 
+def test_rt_multi_builds_the_scene_once_whatever_the_number_of_contexts(rtx, oracle):
+    """Eight contexts on device 0: the uploads go to the first context, which builds the scene (one BVH build); the other seven receive
+    the built scene device to device and hold no host copy.  A second upload costs one more build; a camera that leaves the padded extent
+    is handled per context without any build; images stay the oracle's."""
+    b = rtx.scenes.mesh_test_scene(72, 64).build_buffers()
+    params, spheres, tris, infos = b
+    with rtx.MultiTracer([0] * 8) as mt:
+        mt.set_params(params)
+        mt.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+        mt.render(0, 2)
+        got = mt.read_accum()
+        info = mt.info()
+        assert info["numContexts"] == 8 and info["bvhBuilds"] == 1, info
+        assert info["device"] == [0] * 8 and info["peerAccess"] == [1] * 8 and info["lastSetupMs"] > 0.0
+        want, _, _ = oracle.render(*b, 0, 2)
+        assert_bitwise(got, want, "rt_multi x8, scene built once")
+        mt.reset_accum(); mt.render(0, 2)
+        assert mt.info()["bvhBuilds"] == 1                         # rendering again builds nothing
+        # a builder option marks the scene for a rebuild: one more build, fanned out again
+        mt.set_option("max_leaf", 4)
+        mt.reset_accum(); mt.render(0, 2)
+        assert mt.info()["bvhBuilds"] == 2
+        assert_bitwise(mt.read_accum(), want, "rt_multi x8 after a rebuild with other leaves")
+        mt.set_option("max_leaf", 2)
+        # new content: fewer triangles (the first chunk only) — every context must see the new scene
+        infos2 = infos[:1].copy()
+        mt.upload(spheres=spheres, triangles=tris, meshinfo=infos2)
+        mt.reset_accum(); mt.render(3, 1)
+        want2, _, _ = oracle.render(params, spheres, tris, infos2, 3, 1)
+        assert_bitwise(mt.read_accum(), want2, "rt_multi x8 after a second upload")
+        assert mt.info()["bvhBuilds"] == 3
+
+
 def test_rt_multi_error_paths(rtx):
     with pytest.raises(rtx.RtError):
         rtx.MultiTracer([99])
