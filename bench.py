@@ -36,6 +36,19 @@ TRI_BYTES, SPHERE_BYTES, HIT_BYTES, PIXEL_BYTES = 48, 16, 64 + 48, 48
 VMEM_CYCLES_PER_WAVE_LOAD = 16.2     # tools/ubench/vmem_rate.hip (profiles/ubench_r02_vmem_rate.txt): L1-resident dwordx2/x4, per CU
 
 
+def csrc_sha16():
+    """fingerprint of the kernel sources (csrc/ + include/rt.h): stamps the committed PMC passes (profiles/pmc_table.json), so that a
+    pass taken on other kernels than the ones running is flagged instead of silently multiplied with a live time"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "ray-tracing-extended_amd", "csrc")
+    for f in sorted(os.listdir(base)):
+        if f.endswith((".hpp", ".hip", ".cpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(base, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "rt.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,39 +213,35 @@ def main():
     barrier()
     t0 = time.perf_counter()
     tr.render(0, args.steps)
+    gather_ms = 0.0
     if dist is not None:
+        tg = time.perf_counter()
         tr.copy_accum_to_device(strip.data_ptr(), nrows * W * 4)
         image = gather(strip.to(comm_dev), H, dist)   # [H, W, 4] on rank 0
+        if comm_dev != "cpu":
+            torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
     barrier()
     dt = time.perf_counter() - t0
     st = tr.stats()
-    rays = torch.tensor([float(st["rays"]), dt, st["totalKernelMs"]], dtype=torch.float64, device=comm_dev)
-    if dist is not None:
-        tmax = rays.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        total_rays, wall = rays[0].item(), tmax[1].item()
-    else:
-        total_rays, wall = rays[0].item(), dt
+    job = rtx.distributed.job_report(dist, comm_dev, args.backend if dist is not None else None, float(st["rays"]), dt, st["totalKernelMs"],
+                                     gather_ms, strip.numel() * 4)
+    total_rays, wall = job["total_rays"], job["wall_s"]
+    if job["world_seen"] != world:
+        raise SystemExit(f"the {args.backend} process group has {job['world_seen']} ranks, WORLD_SIZE says {world}")
     kernel_ms_rank0 = st["totalKernelMs"]
-    busy = [round(kernel_ms_rank0, 3)]
-    if dist is not None:                       # per-GPU busy time (load balance of the decomposition)
-        mine = torch.tensor([st["totalKernelMs"]], dtype=torch.float64, device=comm_dev)
-        allb = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allb, mine)
-        busy = [round(b.item(), 3) for b in allb]
+    busy = job["per_rank"]["kernel_ms"]
 
     # ---- roofline (rank 0's strip): counting build of the same kernel over the same K frames, untimed
     roofline = None
     kernel_names = ({1: "k_stream<false,true,{H}>"} if args.rng == "philox" else
-                    {0: "k_trace<false,false,false,{H}>", 1: "k_stream<false,false,{H}>", 2: "k_pool<false>", 3: "k_wave<false>"})
+                    {0: "k_trace<false,false,{H}>", 1: "k_stream<false,false,{H}>", 2: "k_pool<false>", 3: "k_wave<false>"})
     chosen = st.get("lastKernel", -1)                    # the kernel that ran the timed launches
     opts = dict(kv.split("=") for kv in args.opt)
     compact = int(opts.get("compact_nodes", 1)) != 0
-    kernel_name = kernel_names.get(chosen, "k_trace<false,false,true,{H}>" if args.rng == "philox" else "k_trace<false,false,false,{H}>").replace(
-        "{H}", "true" if compact else "false")
+    kernel_name = kernel_names.get(chosen, "k_trace<false,false,{H}>").replace("{H}", "true" if compact else "false")
     if len(tris) == 0 and kernel_name.startswith("k_trace"):
-        kernel_name = kernel_name.replace(",true>", ",false,6>").replace(",false>", ",false,6>")      # spheres only: the six-waves-per-SIMD instantiation
+        kernel_name = "k_trace<false,false,false,6>"                      # spheres only: the six-waves-per-SIMD instantiation
     if not args.no_roofline:
         tr.reset_accum()
         tr.render_counting(0, args.steps)
@@ -250,26 +259,26 @@ def main():
         # any --steps scales them; only for the N = 1 launch they were measured on
         pmc, traffic = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_table.json")
-        if os.path.exists(tf) and world == 1:
+        if os.path.exists(tf):
             try:
                 table = json.load(open(tf))
             except Exception:
                 table = {}
-            exact = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}"
-            ent = table.get(exact) if nrows == H else None
+            sfx = "_philox" if args.rng == "philox" else ""
+            exact = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}{sfx}"
+            ent = table.get(exact) if (nrows == H and world == 1) else None
             if ent is None:
-                # the same scene at another resolution / ray count, or a part of the image (--as-rank-of): the per-frame figures of
-                # its committed pass, scaled by rays (the instruction and byte counts per ray of a scene do not depend on the image size)
+                # the same scene at another resolution / ray count, or a part of the image (a rank of N, --as-rank-of): the per-frame figures
+                # of its committed pass, scaled by rays (the instruction and byte counts per ray of a scene do not depend on the image size)
                 for key, cand in sorted(table.items(), key=lambda kv: kv[0] != exact):
-                    if key.startswith(f"config{args.config}_") and cand.get("rays_per_frame") and sc["rays"] and args.steps:
+                    if key.startswith(f"config{args.config}_") and key.endswith("_philox") == bool(sfx) and cand.get("rays_per_frame") and sc["rays"] and args.steps:
                         k = (sc["rays"] / args.steps) / cand["rays_per_frame"]
                         ent = {f: (v * k if f.endswith("_per_frame") and isinstance(v, (int, float)) else v) for f, v in cand.items()}
                         ent["source"] = f"{cand.get('source')}; scaled by rays per frame x{k:.4f} from {key}"
                         break
             if ent and ent.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
-                pmc = ent
-                if args.rng != "pcg":       # the committed passes ran the reference's PCG stream; Philox issues more instructions per draw
-                    pmc = dict(ent, source=f"{ent.get('source')}; pass of the PCG stream: a lower bound for the Philox mode")
+                pmc = dict(ent)
+                pmc["stale"] = ent.get("csrc_sha16") != csrc_sha16()      # the pass ran other kernel sources than the ones timed here
                 traffic = int(ent["hbm_bytes_per_frame"] * fpl)
         hbm = {"peak": PEAK_HBM_GBPS, "unit": "GB/s",
                "algorithmic_survey_32B_nodes": round(alg_bytes(NODE_BYTES_SURVEY) / launch_s / 1e9, 1),
@@ -278,12 +287,34 @@ def main():
                "measured": round(traffic / launch_s / 1e9, 1) if traffic else None,
                "measured_frac": round(traffic / launch_s / 1e9 / PEAK_HBM_GBPS, 5) if traffic else None}
         hbm["algorithmic_survey_frac"] = round(hbm["algorithmic_survey_32B_nodes"] / PEAK_HBM_GBPS, 5)
-        roofline = {"bound": "valu", "unit": "TFLOP/s", "peak": PEAK_VALU_TFLOPS, "achieved": None, "frac": None,
-                    "traffic": traffic, "kernel": kernel_name, "frames_interleaved_per_wave": st.get("lastFramesInterleaved", 1), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl,
+        # What binds k_stream (round 3, profiles/ab_probe_r03.txt + profiles/ubench_r03_node_mix.txt): instruction ISSUE, on two ports at once.
+        # One more vector-memory instruction per node step costs 5.2 % (13-15 % for two), thirteen more VALU instructions 2.6 % (4.8 % for
+        # 26), on both triangle workloads; the node step's own instruction mix, run in lockstep on L1-resident data with every lane
+        # active, issues 0.244 VALU wave-instructions per cycle and SIMD at five waves (344.8 cycles per step of 84 VALU + 5 loads + 4 LDS)
+        # against the 0.5 of the spec — most of it is half-rate (f16->f32 FMAs, min/max, compares, selects).  So the line reports
+        # the VALU issue rate against the spec AND the share of the launch that the kernel's node steps and triangle tests would take at
+        # the micro-benchmark's rates, the vector-memory issue share, and the HBM contract figures of SURVEY 8(d) (cache-served).
+        MIX = {"node_step_cycles_per_simd": 344.8, "valu_per_node_step": 84, "triangle_test_cycles_per_simd": 264.7, "valu_per_triangle_test": 65,
+               "waves_per_simd": 5, "source": "profiles/ubench_r03_node_mix.txt (tools/ubench/node_mix.hip: the product's node_step<true> / ray_triangle, "
+                                               "all lanes active, data in L1)"}
+        PROBES = {"plus_1_load_per_node_step": {"config3": -0.052, "config5": -0.052}, "plus_2_loads_per_node_step": {"config3": -0.133, "config5": -0.153},
+                  "plus_13_valu_per_node_step": {"config3": -0.026, "config5": -0.028}, "plus_26_valu_per_node_step": {"config3": -0.048},
+                  "plus_1_load_per_triangle_test": {"config3": -0.017, "config5": -0.014}, "plus_13_valu_per_triangle_test": {"config3": -0.013, "config5": -0.011},
+                  "source": "profiles/ab_probe_r03.txt (A/B builds on one box, bench.py --steps 16; throughput change)"}
+        execs = {n: e for n, e in zip(("node", "triangle", "shade", "environment", "camera"), sc["phaseExecs"])}
+        simd_cycles = launch_s * launches * 2.4e9 * 1024                     # SIMD cycles of the timed launches at the nominal clock
+        roofline = {"bound": "issue", "unit": "Gwave-instr/s", "peak": round(PEAK_VALU_WAVE_INSTR / 1e9, 1), "achieved": None, "frac": None,
+                    "traffic": traffic, "kernel": kernel_name, "frames_interleaved_per_wave": st.get("lastFramesInterleaved", 1),
+                    "sample_lanes_per_pixel": st.get("lastSampleLanes", 1), "launch_ms": round(launch_s * 1e3, 3), "frames_per_launch": fpl,
                     "launches": launches, "algorithmic_bytes_per_launch": int(loaded),
-                    "definition": "bound = VALU issue: achieved = VALU wave-instructions/s (SQ_INSTS_VALU per frame from the committed "
-                                  "rocprofv3 pass x frames / launch time measured here) x 64 lanes x 2, against the FP32 vector peak; "
-                                  "the working set is cache-resident, so HBM is not the roof (see hbm)",
+                    "definition": "bound = instruction issue (VALU and vector-memory ports together, see probes): achieved = VALU wave-instructions/s "
+                                  "(SQ_INSTS_VALU per frame from the committed rocprofv3 pass x frames / launch time measured here), peak = the spec's one "
+                                  "wave64 instruction per 2 cycles per SIMD; traversal_at_mix_ceiling = share of the launch's SIMD cycles that its node "
+                                  "steps and triangle tests take at the rates their instruction mix reaches in the micro-benchmark; the working set is "
+                                  "cache-resident, so HBM is not the roof (hbm)",
+                    "traversal_at_mix_ceiling": round((execs["node"] * MIX["node_step_cycles_per_simd"] + execs["triangle"] * MIX["triangle_test_cycles_per_simd"])
+                                                      / simd_cycles, 4) if kernel_name.startswith("k_stream") else None,
+                    "mix_ceiling": MIX, "probes": PROBES,
                     "hbm": hbm,
                     "per_ray": {"nodes": round(sc["nodeVisits"] / max(sc["rays"], 1), 2),
                                 "tris": round(sc["triTests"] / max(sc["rays"], 1), 2),
@@ -298,17 +329,19 @@ def main():
                     "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]}, "pmc": None}
         if pmc:
             instr_s = pmc["valu_wave_instructions_per_frame"] * fpl / launch_s
-            roofline["achieved"] = round(instr_s * 64 * 2 / 1e12, 2)
+            roofline["achieved"] = round(instr_s / 1e9, 2)
             roofline["frac"] = round(instr_s / PEAK_VALU_WAVE_INSTR, 5)
+            roofline["tflops_equivalent"] = {"achieved": round(instr_s * 64 * 2 / 1e12, 2), "peak": PEAK_VALU_TFLOPS,
+                                             "note": "every VALU instruction counted as one FMA per lane: a reference line, not flops"}
             lane = pmc.get("valu_lane_utilisation")
             loads_s = pmc["vmem_read_wave_instructions_per_frame"] * fpl / launch_s
             roofline["frac_active_lanes"] = round(roofline["frac"] * lane, 5) if lane else None
             roofline["vector_memory"] = {"wave_loads_per_s": round(loads_s, 0), "cycles_per_wave_load_per_cu": VMEM_CYCLES_PER_WAVE_LOAD,
                                          "frac": round(loads_s * VMEM_CYCLES_PER_WAVE_LOAD / (256 * 2.4e9), 5)}
-            roofline["pmc"] = {k: pmc.get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "wait_any_frac_of_wave_cycles",
-                                                        "wait_inst_any_frac_of_wave_cycles", "source")}
+            roofline["pmc"] = {k: pmc.get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "td_busy_frac", "wait_any_frac_of_wave_cycles",
+                                                        "wait_inst_any_frac_of_wave_cycles", "csrc_sha16", "stale", "source")}
         else:
-            # no PMC table for this configuration / kernel: the HBM contract figure with the survey's literal bytes stays a bound <= 1
+            # no PMC pass for this configuration / kernel: the HBM contract figure with the survey's literal bytes stays a bound <= 1
             roofline.update({"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS, "achieved": hbm["algorithmic_survey_32B_nodes"],
                              "frac": hbm["algorithmic_survey_frac"],
                              "definition": "no committed PMC pass for this configuration: SURVEY 8(d) algorithmic bytes (32-B nodes) / launch time; "
@@ -364,6 +397,7 @@ def main():
                    "rays_per_frame": int(total_rays / max(args.steps, 1)),
                    "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres)),
                    "per_gpu_kernel_ms": busy},
+        "per_rank": job["per_rank"], "comm": job["comm"],
         "roofline": roofline, "cpu_baseline": cpu,
     }
     if latency:

@@ -72,3 +72,28 @@ def gather_image_banded(strip, height: int, dist=None, dst: int = 0):
         if rows:
             image[torch.as_tensor(rows, device=strip.device)] = bufs[r][:len(rows)]
     return image
+
+
+# ---- the N-rank job's numbers for bench.py's JSON line --------------------------------------------------------------------
+def job_report(dist, comm_device, backend: str, rays: float, wall_s: float, kernel_ms: float, gather_ms: float, strip_bytes: int) -> dict:
+    """Every rank contributes (rays traced, wall seconds of the timed region, kernel ms, ms spent in the gather call, bytes of its strip);
+    returns on EVERY rank: total rays, wall = the slowest rank's, and — for the line's `comm` and `per_rank` objects — what each rank saw.
+    `world_seen` is the world size the backend itself reports (what RCCL / gloo initialised with), so a line cannot claim more GPUs than
+    took part.  dist = None: a single process."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"total_rays": rays, "wall_s": wall_s, "world_seen": 1,
+                "per_rank": {"rays": [int(rays)], "kernel_ms": [round(kernel_ms, 3)], "wall_ms": [round(wall_s * 1e3, 3)]},
+                "comm": {"backend": None, "world_seen": 1, "gather_ms": 0.0, "gather_ms_per_rank": [0.0], "bytes": 0}}
+    world = dist.get_world_size()
+    mine = torch.tensor([float(rays), float(wall_s), float(kernel_ms), float(gather_ms), float(strip_bytes)], dtype=torch.float64, device=comm_device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    rows = [t.tolist() for t in every]
+    return {"total_rays": sum(r[0] for r in rows), "wall_s": max(r[1] for r in rows), "world_seen": world,
+            "per_rank": {"rays": [int(r[0]) for r in rows], "kernel_ms": [round(r[2], 3) for r in rows], "wall_ms": [round(r[1] * 1e3, 3) for r in rows]},
+            "comm": {"backend": backend, "world_seen": world, "gather_ms": round(max(r[3] for r in rows), 3),
+                     "gather_ms_per_rank": [round(r[3], 3) for r in rows],
+                     "bytes": int(sum(r[4] for r in rows[1:])),              # what travels: every strip but the root's own
+                     "note": "one gather to rank 0 at the end of the timed region (N - 1 point-to-point transfers); gather_ms = the slowest rank's "
+                             "time inside the collective call, waiting for the other ranks included"}}

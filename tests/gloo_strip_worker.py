@@ -32,4 +32,15 @@ img = rtx.distributed.gather_image_banded(strip, H, dist)
 if rank == 0:
     assert np.array_equal(img.numpy().view(np.uint32), full2.view(np.uint32)), "banded image differs"
     print("GLOO_BANDS_OK")
+# ---- bench.py's N > 1 numbers: every rank reports, every rank gets the same totals; the world size is the backend's own
+rep = rtx.distributed.job_report(dist, "cpu", "gloo", rays=1000.0 * (rank + 1), wall_s=0.5 + 0.25 * rank, kernel_ms=400.0 + rank, gather_ms=2.0 + rank,
+                                 strip_bytes=per * W * 16)
+assert rep["world_seen"] == world == rep["comm"]["world_seen"] and rep["comm"]["backend"] == "gloo"
+assert rep["total_rays"] == sum(1000.0 * (r + 1) for r in range(world)) and rep["wall_s"] == 0.5 + 0.25 * (world - 1)
+assert rep["per_rank"]["rays"] == [1000 * (r + 1) for r in range(world)] and len(rep["per_rank"]["kernel_ms"]) == world
+assert rep["comm"]["gather_ms"] == 2.0 + (world - 1) and rep["comm"]["bytes"] == (world - 1) * per * W * 16
+import json
+json.dumps(rep)
+if rank == 0:
+    print("GLOO_JOB_REPORT_OK")
 dist.destroy_process_group()

@@ -282,3 +282,56 @@ def test_render_scene_tool_writes_what_the_tracer_holds(rtx, tracer, tmp_path):
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(90, 1 + 160 * 3)
     assert (rows[:, 0] == 0).all()
     assert (rows[:, 1:].reshape(90, 160, 3) == disp[::-1, :, :3]).all()
+
+
+# ---- the counter-based mode at BASELINE's sizes (rt_params.rngMode = RT_RNG_PHILOX: per-sample counters, 16 sample lanes per pixel, the
+# estimator's tree in the wave) against its oracle twin ----
+
+def _philox(m):
+    params, spheres, tris, infos = m.build_buffers()
+    params = params.copy()
+    params["rngMode"] = 1
+    return params, spheres, tris, infos
+
+
+def test_philox_headline_frame_vs_oracle(rtx, oracle, tracer):
+    """configs[2] exactly as benchmarked with --rng philox (1920x1080, 100,440 triangles, 64 rays per pixel, 8 bounces): every pixel of a
+    whole frame equals the oracle twin's, and so does the ray count (~2.4e8)."""
+    b = _philox(rtx.scenes.config3())
+    _, got = run_gpu(tracer, b, 4, 1, kernel=1)
+    st = tracer.stats()
+    want, cnt = oracle.render_frame(*b, 4, accel=True)
+    assert st["lastSampleLanes"] == 16
+    assert_bitwise(got, want, "philox, config3 1080p x64 vs oracle")
+    assert st["rays"] == cnt["rays"] > 200_000_000
+
+
+def test_philox_config2_full_size_vs_oracle(rtx, oracle, tracer):
+    """configs[1] (12 spheres, 1920x1080, 64 rays per pixel, 8 bounces) in Philox mode: a whole frame (~3.4e8 rays) against the oracle twin."""
+    b = _philox(rtx.scenes.config2())
+    _, got = run_gpu(tracer, b, 1, 1, kernel=-1)
+    st = tracer.stats()
+    want, cnt = oracle.render_frame(*b, 1)
+    assert st["lastKernel"] == 1 and st["lastSampleLanes"] == 16
+    assert_bitwise(got, want, "philox, config2 1080p x64 vs oracle")
+    assert st["rays"] == cnt["rays"] > 300_000_000
+
+
+def test_philox_million_triangle_full_hd_vs_oracle(rtx, oracle, tracer):
+    """configs[4] in Philox mode: 1,004,364 triangles, depth of field on (the defocus draws of block 0), 1920x1080, whole frame, 4 rays per
+    pixel (4 sample lanes per pixel), two frames accumulated in one launch."""
+    m = rtx.scenes.config5()
+    m.numRaysPerPixel = 4
+    b = _philox(m)
+    acc, _ = run_gpu(tracer, b, 0, 2, kernel=1)
+    st = tracer.stats()
+    want, total = None, 0
+    for f in range(2):
+        cur, cnt = oracle.render_frame(*b, f, accel=True)
+        if want is None:
+            want = np.zeros_like(cur)
+        oracle.accumulate(want, cur, f)
+        total += cnt["rays"]
+    assert st["lastSampleLanes"] == 4 and st["lastFramesPerLaunch"] == 2
+    assert_bitwise(acc, want, "philox, config5 1080p x4, two frames")
+    assert st["rays"] == total

@@ -8,7 +8,10 @@ import os
 import sys
 
 tag, config, W, H, rays, fpl = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+suffix = sys.argv[7] if len(sys.argv) > 7 else ""            # "_philox" for the counter-based mode
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import csrc_sha16
 s = json.load(open(os.path.join(root, "profiles", f"{tag}_summary.json")))
 c, d = s["pmc_per_full_launch_mean"], s["derived"]
 full = [k for k in s["kernel_stats"] if s["kernel_filter"] in k["Name"]]
@@ -27,15 +30,15 @@ ent = {
     "valu_lane_utilisation": d.get("valu_lane_utilisation"), "ta_busy_frac": d.get("ta_busy_frac"), "td_busy_frac": d.get("td_busy_frac"),
     "wait_any_frac_of_wave_cycles": d.get("SQ_WAIT_ANY_frac_of_wave_cycles"),
     "wait_inst_any_frac_of_wave_cycles": d.get("SQ_WAIT_INST_ANY_frac_of_wave_cycles"),
+    "valu_wave_instr_per_simd_cycle": d.get("valu_wave_instr_per_simd_cycle"), "vmem_issue_frac_per_cu": d.get("vmem_issue_frac_per_cu"),
+    "csrc_sha16": csrc_sha16(),        # the kernels this pass ran: bench.py flags the entry as stale when the sources have changed since
     "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc, one counter group per pass; mean over the {fpl}-frame launches of each pass)",
 }
-# rays per frame of this workload (from its committed bench line): lets bench.py scale the entry to another resolution of the same scene
-bj = os.path.join(root, "profiles", f"bench_r02_config{config}.json")
-if os.path.exists(bj):
-    bd = json.loads(open(bj).read().strip().splitlines()[-1])
-    ent["rays_per_frame"] = round(bd["value"] * 1e6 * bd["ms_per_step"] * 1e-3)
+# rays per frame of this workload (the bench line printed under the stats pass): lets bench.py scale the entry to another resolution or part of the image
+if d.get("rays_per_frame"):
+    ent["rays_per_frame"] = d["rays_per_frame"]
 path = os.path.join(root, "profiles", "pmc_table.json")
 table = json.load(open(path)) if os.path.exists(path) else {}
-table[f"config{config}_{W}x{H}_{rays}"] = ent
+table[f"config{config}_{W}x{H}_{rays}{suffix}"] = ent
 json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(ent, indent=1))

@@ -56,7 +56,15 @@ if "GRBM_GUI_ACTIVE" in c:
     # SQ_* / TA_* sums are per shader engine (32 per chip on MI355X), GRBM_GUI_ACTIVE is summed over the 8 XCDs: /32 gives the
     # per-SIMD (resp. per-TA) busy fraction of the launch, as in profiles/hbm_traffic.json
     if "SQ_ACTIVE_INST_VALU" in c:
-        d["valu_active_frac_per_simd"] = c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] * 32)
+        # SQ_ACTIVE_INST_VALU sums, over the WAVES of a SIMD, the (quad-)cycles in which the wave has a VALU instruction in flight: with
+        # several waves per SIMD it exceeds the SIMD's own cycles (up to waves-per-SIMD times) — it is not a busy fraction
+        d["valu_active_wave_cycles_per_simd_cycle"] = c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] * 32)
+    if "SQ_INSTS_VALU" in c:
+        # VALU wave-instructions issued per SIMD cycle (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs): spec peak 0.5
+        d["valu_wave_instr_per_simd_cycle"] = c["SQ_INSTS_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)
+    if "SQ_INSTS_VMEM_RD" in c:
+        # vector-memory read instructions per CU cycle x 16.2 cycles each (tools/ubench/vmem_rate.hip): share of the CU's vector-memory issue
+        d["vmem_issue_frac_per_cu"] = c["SQ_INSTS_VMEM_RD"] * 16.2 / (c["GRBM_GUI_ACTIVE"] / 8 * 256)
     if "TA_TA_BUSY_sum" in c:
         d["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] * 32)
     if "TD_TD_BUSY_sum" in c:
@@ -65,6 +73,13 @@ if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
     d["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1)
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     d["hbm_bytes_per_full_launch"] = c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024
+log = os.path.join(src, "stats.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{") and '"metric"' in line:
+            b = json.loads(line)
+            out["bench_line_under_rocprof"] = {k: b[k] for k in ("value", "ms_per_step", "steps", "config")}
+            d["rays_per_frame"] = b["config"]["rays_per_frame"]
 out["derived"] = d
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
