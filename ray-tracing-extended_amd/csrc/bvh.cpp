@@ -243,6 +243,41 @@ void pad_box(const Box& b, float G, float* mn, float* mx)
 
 } // namespace
 
+// Binned-SAH binary tree over n boxes (lo.xyz, hi.xyz), every box a leaf of its own — the top of the device builder's tree over the
+// clusters its bottom-up rounds have formed (rt_bvh_gpu.hpp): out[k] = (left, right), a child >= 0 is box index, a child < 0 is ~(index
+// into out); out[0] is the root (n >= 2).  Same split search as `build`, large-box isolation included; weights = one per box.
+void build_over_boxes(const float* boxes, uint32_t n, const Tuning& tuning, std::vector<int32_t>& out)
+{
+    out.clear();
+    if (n < 2) return;
+    Builder B; B.pos = nullptr; B.stride = 0; B.n = n;
+    B.max_leaf = 1;
+    B.g_bins = std::min(std::max(tuning.bins, 2), 128);
+    B.g_cost_exp = (float)std::min(std::max(tuning.cost_exp_percent, 10), 300) / 100.0f;
+    B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.idx.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        Box b;
+        for (int a = 0; a < 3; ++a) { b.mn[a] = boxes[6 * (size_t)i + a]; b.mx[a] = boxes[6 * (size_t)i + 3 + a]; }
+        B.tbox[i] = b;
+        for (int a = 0; a < 3; ++a) {
+            const float c = 0.5f * b.mn[a] + 0.5f * b.mx[a];
+            B.cent[3 * (size_t)i + a] = (c == c && std::fabs(c) < 3.0e38f) ? c : 0.0f;      // (an empty or NaN box still gets a place)
+        }
+        B.idx[i] = i;
+    }
+    B.bn.reserve(2 * (size_t)n);
+    const int root = B.build_range(0, n, 0);
+    // internal nodes in pre-order: bn[root] first
+    std::vector<int32_t> slot(B.bn.size(), -1);
+    int32_t next = 0;
+    for (size_t i = 0; i < B.bn.size(); ++i) if (B.bn[i].count == 0) slot[i] = next++;
+    out.assign(2 * (size_t)next, 0);
+    auto ref = [&](int node) -> int32_t { return B.bn[node].count ? (int32_t)B.idx[B.bn[node].first] : ~slot[node]; };
+    for (size_t i = 0; i < B.bn.size(); ++i)
+        if (B.bn[i].count == 0) { out[2 * (size_t)slot[i]] = ref(B.bn[i].left); out[2 * (size_t)slot[i] + 1] = ref(B.bn[i].right); }
+    (void)root;          // (build_range numbers the root 0, so slot[root] = 0)
+}
+
 void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, const Tuning& tuning, Bvh& out)
 {
     const int g_reinsert_passes = std::min(std::max(tuning.reinsert_passes, 0), 16);

@@ -95,4 +95,9 @@ struct Tuning { int bins = 32; int cost_exp_percent = 100; int reinsert_passes =
 // outside the triangles can have (the camera, sphere surfaces): it widens the absolute part of the box padding.
 void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float origin_magnitude, const Tuning& tuning, Bvh& out);
 
+// The same split search over n boxes (6 floats each: lo.xyz, hi.xyz), one leaf per box: the top of the device builder's tree over the
+// clusters its bottom-up rounds have formed.  out = pairs (left, right) of the internal nodes, out[0..1] the root; a child >= 0 is a box
+// index, a child < 0 is ~(internal node index).
+void build_over_boxes(const float* boxes, uint32_t n, const Tuning& tuning, std::vector<int32_t>& out);
+
 } // namespace rtbvh

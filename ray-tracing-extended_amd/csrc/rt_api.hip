@@ -115,6 +115,8 @@ struct rt_ctx {
     int opt_bvh_radius = 8;         // device builder: PLOC search radius of the first rounds; doubled once a quarter, again once a sixteenth of
                                     // the clusters is left (negative = that radius in every round).  Work per ray against the host tree at
                                     // 100k / 1M triangles: 8 -> 1.10 / 1.05, 12 -> 1.10 / 1.09, 16 -> 1.10 / 1.17, fixed 16 -> 1.07 / 1.13
+    int opt_bvh_top = 1024;         // device builder: once the bottom-up rounds have left at most this many clusters, the top of the tree is built by the
+                                    // host's binned-SAH split search over their boxes (a few hundred KB and about a millisecond; 0 = clustering to the root)
     int opt_rebuild_percent = 200;  // device pipeline: rebuild instead of refit once the internal area exceeds this share of the build's
     int n_cu = 0;
     int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream, 2: k_pool
@@ -244,7 +246,8 @@ int device_build(rt_ctx* c, uint32_t nt, float origin_magnitude)
     RT_HIP(c, c->d_tri_geo.ensure(3 * (size_t)nt)); RT_HIP(c, c->d_tri_nrm.ensure(3 * (size_t)nt));
     RT_HIP(c, hipEventRecord(c->evg0, c->stream));
     rtgb::Result res;
-    RT_HIP(c, rtgb::build(c->stream, c->d_raw_tris.p, nt, origin_magnitude, c->opt_bvh_radius, c->bvh_ws, reinterpret_cast<rtbvh::Node4*>(c->d_nodes.p), c->d_order.p, res));
+    RT_HIP(c, rtgb::build(c->stream, c->d_raw_tris.p, nt, origin_magnitude, c->opt_bvh_radius, c->bvh_ws, reinterpret_cast<rtbvh::Node4*>(c->d_nodes.p), c->d_order.p, res,
+                          (uint32_t)c->opt_bvh_top, bvh_tuning(c)));
     c->bvh.nodes.clear(); c->bvh.order.clear();
     c->n_nodes = res.n_nodes; c->bvh.levelStart = res.level_start; c->bvh.maxStack = res.max_stack; c->bvh.magnitude = res.magnitude;
     c->bvh.depth = res.levels;
@@ -457,16 +460,18 @@ int run_geometry_kernels(rt_ctx* c, bool have_bvh)
         { int r = compact_nodes(c); if (r) return r; }
     }
     RT_HIP(c, hipGetLastError());
+    // a refit keeps the topology: meshes that moved apart leave boxes that overlap more and more.  The refitted tree's internal area is
+    // summed in the same pass (one more small kernel and a 4-byte copy before the one synchronisation, inside lastGeometryMs); once it
+    // has grown past the threshold the tree is rebuilt on the device (cheaper than one frame) instead of refitted.
+    const bool check_area = have_bvh && nt && c->opt_device_bvh != 0 && c->opt_rebuild_percent > 0 && c->area_at_build > 0.f;
+    float area = 0.f;
+    if (check_area) RT_HIP(c, rtgb::internal_area_async(c->stream, reinterpret_cast<const rtbvh::Node4*>(c->d_nodes.p), (uint32_t)c->n_nodes, c->bvh_ws, &area));
     RT_HIP(c, hipEventRecord(c->evg1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
     c->stats.lastGeometryMs = ms;
-    if (have_bvh && nt && c->opt_device_bvh != 0 && c->opt_rebuild_percent > 0 && c->area_at_build > 0.f) {
-        // a refit keeps the topology: meshes that moved apart leave boxes that overlap more and more.  Once the internal area has
-        // grown past the threshold the tree is rebuilt on the device (cheaper than one frame) instead of refitted.
-        float area = 0.f;
-        RT_HIP(c, rtgb::internal_area(c->stream, reinterpret_cast<const rtbvh::Node4*>(c->d_nodes.p), (uint32_t)c->n_nodes, c->bvh_ws, area));
+    if (check_area) {
         c->stats.refitAreaRatio = area / c->area_at_build;
         if (area > c->area_at_build * (float)c->opt_rebuild_percent / 100.0f) {
             int r = device_build(c, nt, local_scene_magnitude(c)); if (r) return r;
@@ -1145,6 +1150,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "compact_nodes")) c->opt_compact_nodes = value ? 1 : 0;
     else if (!std::strcmp(name, "device_bvh")) { if (value < -1 || value > 1) return fail(c, -2, "device_bvh must be -1 (automatic), 0 or 1"); if (value != c->opt_device_bvh) c->scene_dirty = true; c->opt_device_bvh = value; }
     else if (!std::strcmp(name, "bvh_radius")) { if (value == 0 || value < -rtgb::kMaxRadius || value > rtgb::kMaxRadius) return fail(c, -2, "bvh_radius must be in [1,64] (negative: the same radius in every round)"); if (value != c->opt_bvh_radius) c->scene_dirty = true; c->opt_bvh_radius = value; }
+    else if (!std::strcmp(name, "bvh_top")) { if (value < 0 || value > (1 << 20)) return fail(c, -2, "bvh_top must be in [0,1048576] (0 = the device's clustering builds the whole tree)"); if (value != c->opt_bvh_top) c->scene_dirty = true; c->opt_bvh_top = value; }
     else if (!std::strcmp(name, "rebuild_percent")) { if (value < 0 || value > 100000) return fail(c, -2, "rebuild_percent must be in [0,100000] (0 = never rebuild)"); c->opt_rebuild_percent = value; }
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;

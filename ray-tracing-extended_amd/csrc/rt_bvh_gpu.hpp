@@ -274,6 +274,34 @@ __global__ __launch_bounds__(kPlocBlock) void k_ploc_tail(const uint32_t* __rest
     if (t == 0) ctr[kCtrClusters + 1] = sid[0];
 }
 
+// ---- 3b. the top of the tree: the last `m` clusters go to the host as boxes, a binned-SAH split search builds the binary tree over
+// them (bvh.cpp build_over_boxes: the upper levels decide most of a ray's node visits, and a top-down SAH places them better than
+// bottom-up clustering does), and its nodes come back as (left, right) pairs.
+__global__ __launch_bounds__(256) void k_cluster_boxes(const uint32_t* __restrict__ cin, uint32_t m, const float4* __restrict__ bmin,
+                                                       const float4* __restrict__ bmax, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float4 lo = bmin[cin[i]], hi = bmax[cin[i]];
+    float* o = out + 6 * (size_t)i;
+    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = hi.x; o[4] = hi.y; o[5] = hi.z;
+}
+// pairs: the host's internal nodes (child >= 0: index into cin, child < 0: ~(host node)); host node k becomes binary node base + k.
+// One launch per depth is not needed: a node's box is the union of the boxes of the clusters below it, which the host has computed
+// and sends along (boxes: 6 floats per host node).
+__global__ __launch_bounds__(256) void k_top_nodes(const int32_t* __restrict__ pairs, const float* __restrict__ boxes, uint32_t n_top, uint32_t base,
+                                                   const uint32_t* __restrict__ cin, float4* __restrict__ bmin, float4* __restrict__ bmax,
+                                                   int2* __restrict__ child)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_top) return;
+    const int32_t l = pairs[2 * k], r = pairs[2 * k + 1];
+    child[base + k] = make_int2(l >= 0 ? (int)cin[l] : (int)(base + (uint32_t)~l), r >= 0 ? (int)cin[r] : (int)(base + (uint32_t)~r));
+    const float* b = boxes + 6 * (size_t)k;
+    bmin[base + k] = make_float4(b[0], b[1], b[2], 0.f);
+    bmax[base + k] = make_float4(b[3], b[4], b[5], 0.f);
+}
+
 // ---- 4. collapse to 4-wide nodes, one level per launch --------------------------------------------------------------------
 __device__ __forceinline__ bool leaf_unit(uint32_t x, uint32_t nt, const int2* __restrict__ child)
 {
@@ -391,6 +419,8 @@ template <class T> struct Buf {
 };
 
 struct Workspace {
+    Buf<float> top_boxes; Buf<int32_t> top_pairs;       // the host-built top of the tree (boxes out, nodes back)
+    std::vector<float> h_boxes, h_top_boxes; std::vector<int32_t> h_pairs;
     Buf<uint64_t> keys0, keys1;
     Buf<uint32_t> ids0, ids1, c0, c1, tmp, block_count, block_offset, ctr;
     Buf<unsigned char> sort_tmp;
@@ -403,7 +433,7 @@ struct Workspace {
     {
         keys0.release(); keys1.release(); ids0.release(); ids1.release(); c0.release(); c1.release(); tmp.release(); block_count.release();
         block_offset.release(); ctr.release(); sort_tmp.release(); bmin.release(); bmax.release(); child.release(); f0.release(); f1.release();
-        need.release(); area.release();
+        need.release(); area.release(); top_boxes.release(); top_pairs.release();
     }
 };
 
@@ -418,8 +448,10 @@ struct Result {
 
 // tris: nt world-space triangles (18 floats each) on the device.  nodes: room for nt + 1 Node4 records; order: nt entries.
 // origin_magnitude: largest |coordinate| of a ray origin outside the triangles (camera, spheres).
+// top_clusters: once the bottom-up rounds have left at most this many clusters, the rest of the tree — its top — is built by the
+// host's binned-SAH split search over the clusters' boxes (0: the rounds run down to 512 clusters and one workgroup finishes).
 inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, float origin_magnitude, int radius, Workspace& w,
-                        rtbvh::Node4* nodes, uint32_t* order, Result& out)
+                        rtbvh::Node4* nodes, uint32_t* order, Result& out, uint32_t top_clusters = 0, const rtbvh::Tuning& tuning = rtbvh::Tuning())
 {
     const bool widen = radius > 0;              // a negative radius = that radius in every round (A/B of the schedule)
     radius = std::max(1, std::min(radius < 0 ? -radius : radius, kMaxRadius));
@@ -448,7 +480,8 @@ inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, floa
     // ---- PLOC rounds
     uint32_t m = nt;
     uint32_t* cin = w.c0.p; uint32_t* cout = w.c1.p;
-    while (m > (uint32_t)kPlocBlock) {
+    const uint32_t stop_at = std::max<uint32_t>((uint32_t)kPlocBlock, top_clusters);
+    while (m > stop_at) {
         const uint32_t nb = (m + kPlocBlock - 1) / kPlocBlock;
         // wider search as the clusters get fewer and larger (the upper levels decide most of a ray's node visits, and cost little)
         const int r_now = (widen && m <= nt / 16) ? std::min(kMaxRadius, 4 * radius) : (widen && m <= nt / 4) ? std::min(kMaxRadius, 2 * radius) : radius;
@@ -461,11 +494,43 @@ inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, floa
         if (m_next == 0 || m_next >= m) return hipErrorUnknown;           // (cannot happen: every round merges at least one pair)
         m = m_next; std::swap(cin, cout); ++out.rounds;
     }
-    hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocBlock), 0, stream, cin, m, nt, w.bmin.p, w.bmax.p, w.child.p, w.ctr.p, radius);
     uint32_t root = 0; uint32_t h_bounds[8];
-    RTGB_HIP(hipMemcpyAsync(&root, w.ctr.p + kCtrClusters + 1, sizeof root, hipMemcpyDeviceToHost, stream));
-    RTGB_HIP(hipMemcpyAsync(h_bounds, w.ctr.p + kCtrBounds, sizeof h_bounds, hipMemcpyDeviceToHost, stream));
-    RTGB_HIP(hipStreamSynchronize(stream));
+    if (top_clusters > 0 && m >= 2) {
+        // ---- the top of the tree on the host: m boxes out (24 B each), m - 1 nodes back
+        uint32_t made = 0;
+        RTGB_HIP(w.top_boxes.ensure(6 * (size_t)m)); RTGB_HIP(w.top_pairs.ensure(2 * (size_t)m));
+        hipLaunchKernelGGL(k_cluster_boxes, dim3((m + 255) / 256), dim3(256), 0, stream, cin, m, w.bmin.p, w.bmax.p, w.top_boxes.p);
+        w.h_boxes.resize(6 * (size_t)m);
+        RTGB_HIP(hipMemcpyAsync(w.h_boxes.data(), w.top_boxes.p, w.h_boxes.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipMemcpyAsync(&made, w.ctr.p + kCtrNodes, sizeof made, hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipMemcpyAsync(h_bounds, w.ctr.p + kCtrBounds, sizeof h_bounds, hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipStreamSynchronize(stream));
+        rtbvh::build_over_boxes(w.h_boxes.data(), m, tuning, w.h_pairs);
+        const uint32_t n_top = (uint32_t)(w.h_pairs.size() / 2);            // = m - 1
+        // boxes of the host's nodes, children before parents (pre-order numbering: a child's index is larger than its parent's)
+        w.h_top_boxes.assign(6 * (size_t)n_top, 0.f);
+        for (uint32_t k = n_top; k-- > 0; ) {
+            float* b = &w.h_top_boxes[6 * (size_t)k];
+            for (int a = 0; a < 3; ++a) { b[a] = __builtin_inff(); b[3 + a] = -__builtin_inff(); }
+            for (int side = 0; side < 2; ++side) {
+                const int32_t c = w.h_pairs[2 * (size_t)k + side];
+                const float* cb = c >= 0 ? &w.h_boxes[6 * (size_t)c] : &w.h_top_boxes[6 * (size_t)~c];
+                for (int a = 0; a < 3; ++a) { b[a] = std::fmin(b[a], cb[a]); b[3 + a] = std::fmax(b[3 + a], cb[3 + a]); }
+            }
+        }
+        RTGB_HIP(w.top_boxes.ensure(6 * (size_t)std::max(m, n_top)));
+        RTGB_HIP(hipMemcpyAsync(w.top_pairs.p, w.h_pairs.data(), w.h_pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        RTGB_HIP(hipMemcpyAsync(w.top_boxes.p, w.h_top_boxes.data(), w.h_top_boxes.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_top_nodes, dim3((n_top + 255) / 256), dim3(256), 0, stream, w.top_pairs.p, w.top_boxes.p, n_top, nt + made, cin,
+                           w.bmin.p, w.bmax.p, w.child.p);
+        root = nt + made;                                                   // the host's node 0
+        RTGB_HIP(hipStreamSynchronize(stream));                             // (the staging vectors are reused by the next build)
+    } else {
+        hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocBlock), 0, stream, cin, m, nt, w.bmin.p, w.bmax.p, w.child.p, w.ctr.p, radius);
+        RTGB_HIP(hipMemcpyAsync(&root, w.ctr.p + kCtrClusters + 1, sizeof root, hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipMemcpyAsync(h_bounds, w.ctr.p + kCtrBounds, sizeof h_bounds, hipMemcpyDeviceToHost, stream));
+        RTGB_HIP(hipStreamSynchronize(stream));
+    }
     const float G = std::max(origin_magnitude, ord2f(h_bounds[6]));
     out.magnitude = G;
 
@@ -497,6 +562,17 @@ inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, floa
     RTGB_HIP(hipStreamSynchronize(stream));
     out.max_stack = std::max(1, need0);
     return hipGetLastError();
+}
+
+// the same without the synchronisation: the sum arrives in *host_area once the stream has been synchronised
+inline hipError_t internal_area_async(hipStream_t stream, const rtbvh::Node4* nodes, uint32_t nn, Workspace& w, float* host_area)
+{
+    *host_area = 0.f;
+    if (!nn) return hipSuccess;
+    RTGB_HIP(w.area.ensure(1));
+    RTGB_HIP(hipMemsetAsync(w.area.p, 0, sizeof(float), stream));
+    hipLaunchKernelGGL(k_internal_area, dim3((int)std::min<uint32_t>((nn + 255) / 256, 1024)), dim3(256), 0, stream, nodes, nn, w.area.p);
+    return hipMemcpyAsync(host_area, w.area.p, sizeof(float), hipMemcpyDeviceToHost, stream);
 }
 
 // sum of internal child-box areas of the current nodes (synchronous, one float back)

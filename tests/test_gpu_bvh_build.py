@@ -79,9 +79,9 @@ def test_device_builder_small_and_awkward_triangle_counts(rtx, oracle, tracer, n
 
 
 def test_device_builder_meets_the_build_time_and_quality_bars(rtx, tracer):
-    """100,440 and 1,004,364 triangles: build time (HIP events around sort + clustering + collapse + triangle records + f16 nodes)
-    under 5 ms, traversal work per ray (node visits + triangle tests, counting build, 480x270 x 2 rays) within 15 % of the host's
-    binned-SAH tree, same image."""
+    """100,440 and 1,004,364 triangles: build time (HIP events around sort + clustering + the host-built top of the tree + collapse +
+    triangle records + f16 nodes) under 6 ms, traversal work per ray (node visits + triangle tests, counting build, 480x270 x 2 rays)
+    within 5 % of the host's binned-SAH tree, same image.  The same with the clustering alone (bvh_top = 0): within 15 %."""
     for gen, tri_count in ((rtx.scenes.config3, 100440), (rtx.scenes.config5, 1004364)):
         m = gen(480, 270)
         m.numRaysPerPixel = 2
@@ -93,9 +93,16 @@ def test_device_builder_meets_the_build_time_and_quality_bars(rtx, tracer):
         assert_bitwise(dev_img, host_img, f"{tri_count} triangles: device tree vs host tree")
         work_h = (sh["nodeVisits"] + sh["triTests"]) / sh["rays"]
         work_d = (sd["nodeVisits"] + sd["triTests"]) / sd["rays"]
-        assert sd["bvhBuiltOnDevice"] == 1 and sd["lastBvhBuildMs"] < 5.0, sd["lastBvhBuildMs"]
-        assert work_d <= 1.15 * work_h, (tri_count, work_d, work_h)
+        assert sd["bvhBuiltOnDevice"] == 1 and sd["lastBvhBuildMs"] < 6.0, sd["lastBvhBuildMs"]
+        assert work_d <= 1.05 * work_h, (tri_count, work_d, work_h)
         assert sd["bvhMaxStack"] < 64
+        tracer.set_option("bvh_top", 0)
+        try:
+            ploc_img, sp = _render_with(tracer, b, 1, frames=1, counting=True)
+        finally:
+            tracer.set_option("bvh_top", 1024)
+        assert_bitwise(ploc_img, host_img, f"{tri_count} triangles: clustering-only tree vs host tree")
+        assert (sp["nodeVisits"] + sp["triTests"]) / sp["rays"] <= 1.15 * work_h
 
 
 def test_refit_that_inflates_the_tree_triggers_a_device_rebuild(rtx, tracer):
