@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--rays", type=int, default=0, help="override rays per pixel per frame (default 64)")
-    ap.add_argument("--kernel", type=int, default=-2, help="tuning: -1 automatic (library default), 0 k_trace, 1 k_stream, 2 k_pool")
+    ap.add_argument("--kernel", type=int, default=-2, help="tuning: -1 automatic (library default), 0 k_trace, 1 k_stream")
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option passed to rt_set_option")

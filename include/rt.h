@@ -205,14 +205,14 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
 /* Tuning knobs; the image never depends on them (tested bitwise).
  *   "kernel"          -1 = automatic (default): the first frames after a scene / camera change time k_trace and k_stream on
  *                     ordinary frames of the render and the faster one takes the rest; 0 = tile-per-wave megakernel k_trace,
- *                     1 = k_stream (resumable traversal, stragglers deferred), 2 = k_pool (128 pixel slots per wave in LDS,
- *                     in-wave ballot/prefix-sum compaction), 3 = k_wave (256 pixel slots per wave, path state in global
- *                     memory, phases on compacted slot lists); 2 and 3 are measured alternatives, never picked automatically
+ *                     1 = k_stream (resumable traversal, stragglers deferred; the only kernel of the Philox mode); 2 = k_pool, 3 = k_wave:
+ *                     the two in-wave compaction schedulers of round 1 (-40 % / -28 %), compiled only into builds made with
+ *                     -DRT_EXPERIMENTAL_SCHEDULERS — the product library answers them with an error
  *   "max_leaf"        triangles per BVH leaf, 1..4 (default 2)
  *   "bvh_bins", "bvh_cost_exp", "bvh_reinsert"   BVH builder: SAH bins per axis (32); exponent, in percent, of the triangle
  *                     count in the SAH's subtree-cost model (100); passes of insertion-based optimisation of the binary tree (0:
  *                     measured -3 % node visits per ray but no fewer wave-level steps)
- *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (30 = five workgroups per CU); a BVH whose worst
+ *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (30, with the groups' item tables = five workgroups per CU); a BVH whose worst
  *                     case is deeper spills the rest to global memory
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order
@@ -221,17 +221,21 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "shade_threshold" k_stream: lanes (1..64) with a complete query that end a traversal burst (default 48)
  *   "node_min"        k_stream: inside a burst the node loop goes on while at least this many lanes hold an internal node (or no
  *                     lane holds a leaf); below it the leaves are served first (default 10; 1 = classic while-while)
- *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch while the launch's queue is long; a lane that finishes its pixel of
- *                     one item moves on to its position in the next instead of idling until the item's slowest pixel is done (default 16 = the 16
- *                     sub-tiles of one 8x8 tile when 16 frames are interleaved)
- *   "fetch_guide"     k_stream: guided self-scheduling — groups of tiles_per_fetch items while more than fetch_guide groups per wave of
- *                     the launch are left in the queue, then items_left / (waves x fetch_guide), down to single items (default 4)
+ *   "tiles_per_fetch" k_stream: work items a wave reserves per fetch while the launch's queue is long (1..32, default 16 = the 16 sub-tiles of
+ *                     one 8x8 tile); the units of the group — a pixel's sample chain (PCG) or one sub-stream of a pixel's samples (Philox) —
+ *                     are handed to whichever lanes ask, in order, so nobody waits for the lane that drew the most expensive ones
+ *   "fetch_guide", "fetch_guide_philox"   k_stream: guided self-scheduling — groups of tiles_per_fetch items while more than fetch_guide
+ *                     groups per wave of the launch are left in the queue, then items_left / (waves x fetch_guide), down to single items
+ *                     (default 4 for the PCG stream, 1 in Philox mode, whose units are small)
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
  *   "stream_tile"     k_stream: frames interleaved in a wave, as log2: 0 = 8x8 pixels of one frame, 2 = 4x4 pixels x 4 frames of the
  *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)
  *   "device_bvh"      1 = build the BVH on the device (Morton order, PLOC clustering, breadth-first collapse to 4-wide nodes: 100k
  *                     triangles in 2.0 ms, 1M in 4.3 ms), 0 = the host's binned-SAH builder (50 ms / 600 ms, 5-10 % less traversal
  *                     work per ray), -1 (default) = device for rt_upload_local_meshes (meshes that move), host for world-space uploads
+ *   "bvh_top"         device builder: once its bottom-up rounds have left at most this many clusters, the top of the tree is built by the
+ *                     host's binned-SAH split search over the clusters' boxes (default 1024: work per ray 1.03x / 0.99x the host tree's on the
+ *                     100k- / 1M-triangle workloads, against 1.10x / 1.05x with 0 = clustering up to the root)
  *   "bvh_radius"      device builder: PLOC search radius of the first rounds, 1..64 (default 8); it doubles once a quarter and again once
  *                     a sixteenth of the clusters is left; a negative value keeps |value| in every round
  *   "rebuild_percent" on-device geometry pipeline: after a refit, rebuild on the device once the summed internal box area exceeds

@@ -658,6 +658,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (philox && var == Variant::Flat) return fail(c, -2, "the flat validation kernel implements the PCG stream only");
     if (philox) kernel = 1;
     if (philox && (c->target_w > 65535 || c->target_rows > 65535)) return fail(c, -7, "the Philox mode addresses at most 65535 x 65535 pixels per context");
+    if (philox && (c->params.numRaysPerPixel > 65000 || c->params.maxBounceCount > 65000))
+        return fail(c, -7, "the Philox mode takes at most 65000 rays per pixel per frame and 65000 bounces (16-bit sample and bounce counters)");
     const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1        // PCG or Philox instantiation
                         && c->target_w <= 65535 && c->target_rows <= 65535;                          // (16-bit pixel coordinates in k_stream's item tables)
     const bool pooled = RT_EXPERIMENTAL && !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1

@@ -236,9 +236,11 @@ struct PhiloxScope {
         uint32_t c0 = blk, d1 = c1, c2 = 0, c3 = 0, a = k0, b = k1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
-            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-            c0 = hi1 ^ d1 ^ a; d1 = lo1; c2 = hi0 ^ c3 ^ b; c3 = lo0;
+            // the two 32 x 32 -> 64 products of a round, one v_mad_u64_u32 each: it issues like v_mul_lo_u32 or v_mul_hi_u32 alone (4.4 against
+            // 4.7 + 4.2 cycles, profiles/ubench_r03_valu_rate6.txt) and the compiler emits the pair: a block 308 -> 237 cycles
+            // (written as 64-bit products so that the compiler emits one v_mad_u64_u32 each; __umulhi + the 32-bit product gave two instructions)
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+            c0 = (uint32_t)(p1 >> 32) ^ d1 ^ a; d1 = (uint32_t)p1; c2 = (uint32_t)(p0 >> 32) ^ c3 ^ b; c3 = (uint32_t)p0;
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
         w0 = c0; w1 = d1; w2 = c2; w3 = c3;

@@ -113,18 +113,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
     uint32_t pxy = kNoPixel;            // current pixel: x | local row << 16 (the host keeps k_stream to targets of at most 65535 x 65535); kNoPixel: none
     uint32_t rng = 0u;                  // RT_RNG_PCG: the reference's stream, a serial chain through the pixel's samples and bounces.  RT_RNG_PHILOX keeps
                                         // no generator state at all: a draw is a function of (pixel, frame, sample, bounce) — rtm::PhiloxScope
-    int sample = 0, bounce = 0;
+    int sample = 0, bounce = 0;         // PCG.  PHILOX keeps both in `sample` (sample | bounce << 16: the host refuses more than 65535 of either) — the
+                                        // generator's temporaries need the register in the scatter code
     v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
     RaySlabT<H> slab = make_slab<H>(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));
     uint32_t cur = kNone;
     Hit best; best.t = INF; best.id = kNone; best.u = 0.f; best.v = 0.f;
     bool live = false;                  // a finished closest-hit query is waiting to be shaded
-    unsigned int wave_fi = 0;           // frame (offset into the launch) of this lane's pixel
     unsigned long long wave_t0 = 0;
     unsigned int group_base = 0, group_len = 0;   // items [group_base, group_base + group_len) of the launch's queue belong to this wave
     unsigned int next_unit = 0;                   // ... = 64 * group_len units (item of the group << 6 | position in the item); units below this are taken.
                                                   // Wave-uniform: only ever changed in wave-uniform control flow
-    unsigned int kidx = 0;                        // this lane's unit
+    unsigned int kidx = 0;                        // (per lane) this lane's unit | frame of its pixel (offset into the launch) << 16
     // A unit is what one lane works through before it needs new work: PCG — a pixel of the item with all its samples (the RNG chain);
     // PHILOX — one sub-stream (samples k, k + S, ...) of a pixel.  Units are handed out in order to whichever lanes ask (take_units):
     // the lanes at work always hold a window of consecutive units — neighbouring pixels, the same few items — and the group ends within
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
         const int x = (int)((e.x & 0xFFFFu) + (pix & ((1u << swl) - 1u)));
         const int yy = (int)((e.x >> 16) + (pix >> swl));
         if (!(x < p.width && yy < F.nrows && fi < nframes_)) return false;
-        pxy = (uint32_t)x | ((uint32_t)yy << 16); wave_fi = fi; kidx = id;
+        pxy = (uint32_t)x | ((uint32_t)yy << 16); kidx = id | (fi << 16);
         const uint32_t pixelIndex = (uint32_t)(F.row0 + (yy >> 3) * F.row_stride + (yy & 7)) * W + (uint32_t)x;
-        if constexpr (PHILOX) sample = (int)(pos >> pxl);                                    // this unit's sub-stream: samples k, k + S, ... (S <= NumRaysPerPixel)
+        if constexpr (PHILOX) sample = (int)(pos >> pxl);                                    // (bounce = 0 in the high half) this unit's sub-stream: samples k, k + S, ... (S <= NumRaysPerPixel)
         else { rng = pixelIndex + (uint32_t)(F.frame + (int)fi) * 719393u; sample = 0; }     // :361-362
         total = rtm::mk(0.f, 0.f, 0.f);
         live = false;
@@ -332,14 +332,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             normal = rtm::normalize(hitPoint - rtm::mk(s.x, s.y, s.z));
                             mat = S.sph_mat + (size_t)best.id * 4;
                         }
-                        const float4 mcol = mat[0], memi = mat[1], mspec = mat[2], mprm = mat[3];
+                        const float4 mcol = mat[0], memi = mat[1], mprm = mat[3];      // (specularColour: loaded where it is used, below)
                         const int flag = (int)__float_as_uint(mprm.w);
                         v3 colour = rtm::mk(mcol.x, mcol.y, mcol.z);
                         bool skip = false;
                         if (flag == 1) {                                               // CheckerPattern :313-317
                             float cx = mod2(__builtin_floorf(hitPoint.x)), cz = mod2(__builtin_floorf(hitPoint.z));
                             if (!(cx == cz)) colour = rtm::mk(memi.x, memi.y, memi.z);
-                        } else if (flag == 2 && bounce == 0) {                         // InvisibleLightSource :318-322
+                        } else if (flag == 2 && (PHILOX ? (sample >> 16) : bounce) == 0) {   // InvisibleLightSource :318-322
                             o = hitPoint + d * 0.001f;
                             skip = true;
                         }
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                                 const float specF = isSpecular ? 1.0f : 0.0f;
                                 o = hitPoint;                                              // :327
                                 v3 diffuseDir = rtm::normalize(normal + rtm::random_direction(R));
+                                const float4 mspec = mat[2];           // after the six draws of the direction: three registers fewer across them
                                 v3 specularDir = rtm::reflect(d, normal);
                                 d = rtm::normalize(rtm::lerp(diffuseDir, specularDir, mprm.y * specF));
                                 v3 emitted = rtm::mk(memi.x, memi.y, memi.z) * mprm.x;     // :333-335
@@ -360,12 +361,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             };
                             if constexpr (PHILOX) {
                                 rtm::PhiloxScope R;                                        // the eight draws of this hit: blocks 1 + 2b, 2 + 2b
-                                R.begin(pixel_index(F), (uint32_t)(F.frame + (int)wave_fi), (uint32_t)sample, 1u + 2u * (uint32_t)bounce);
+                                R.begin(pixel_index(F), (uint32_t)F.frame + (kidx >> 16), (uint32_t)sample & 0xFFFFu, 1u + 2u * ((uint32_t)sample >> 16));
                                 scatter(R);
                             } else scatter(rng);
                         }
-                        ++bounce;
-                        if (bounce > p.maxBounceCount) path_done = true;               // loop bound :305
+                        if constexpr (PHILOX) { sample += 0x10000; if ((sample >> 16) > p.maxBounceCount) path_done = true; }
+                        else { ++bounce; if (bounce > p.maxBounceCount) path_done = true; }   // loop bound :305
                     } else {
 #if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 3);
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                     }
                     if (path_done) {
                         total = total + light;                                         // :384
-                        sample += PHILOX ? (1 << A.sample_lanes_log2) : 1;
+                        if constexpr (PHILOX) sample = (sample & 0xFFFF) + (1 << A.sample_lanes_log2); else ++sample;       // (Philox: next sample of the sub-stream, bounce 0)
                         if (PHILOX && sample >= p.numRaysPerPixel) {
                             // ---- this unit (one sub-stream of a pixel) is complete: park its sum (the wave adds the sub-streams up when the
                             // group is done) and ask for the next unit
-                            float* q = park_slot(F, A, kidx >> 6) + (kidx & 63u);
+                            float* q = park_slot(F, A, (kidx & 0xFFFFu) >> 6) + (kidx & 63u);
                             q[0] = total.x; q[64] = total.y; q[128] = total.z;
                             pxy = kNoPixel; want = true;
                         } else if (sample >= p.numRaysPerPixel) {
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                             const size_t pi = (size_t)(pxy >> 16) * W + (pxy & 0xFFFFu);
                             float one = 1.0f;
                             asm volatile("" : "+v"(one));       // (or the 16-byte register tuple of this store is set up, w = 1, at kernel entry and spilled)
-                            F.out_frame[(size_t)wave_fi * F.frame_stride + pi] = make_float4(cx, cy, cz, one);
+                            F.out_frame[(size_t)(kidx >> 16) * F.frame_stride + pi] = make_float4(cx, cy, cz, one);
                             if (F.frames_in_launch <= 1) {
                                 const float weight = 1.0f / (float)(F.frame + 1);              // Accumulate.shader:48
                                 const float omw = 1.0f - weight;
@@ -459,10 +460,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                                                  ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f);
                         if constexpr (PHILOX) {
                             rtm::PhiloxScope R;                                        // the four draws of this sample's camera ray: block 0
-                            R.begin((uint32_t)y * W + (uint32_t)px, (uint32_t)(F.frame + (int)wave_fi), (uint32_t)sample, 0u);
+                            R.begin((uint32_t)y * W + (uint32_t)px, (uint32_t)F.frame + (kidx >> 16), (uint32_t)sample & 0xFFFFu, 0u);
                             camera_ray(p, cam, R, o, d, F.fixed_origin != 0);
                         } else camera_ray(p, cam, rng, o, d, F.fixed_origin != 0);
-                        bounce = 0;
+                        if constexpr (PHILOX) sample &= 0xFFFF; else bounce = 0;
                         rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
                     }
                     {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         if (COUNT && ballot_(cur >= 4u * RT_DIAG_TOP + 1u) == 0ull && (unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[4]++;
 #endif
 #ifdef RT_DIAG_PRIMARY   // diagnostic build only (tools/diag_primary.py): node steps / triangle tests of camera rays (bounce 0) in counters 3 / 4; execs = steps with any such lane
-                        if (COUNT && bounce == 0) { cnt.phase_lanes[3]++; if ((unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[3]++; }
+                        if (COUNT && (PHILOX ? (sample >> 16) : bounce) == 0) { cnt.phase_lanes[3]++; if ((unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[3]++; }
 #endif
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         if (COUNT) cnt.tris++;
                         phase_tick<COUNT>(cnt, 1);
 #ifdef RT_DIAG_PRIMARY
-                        if (COUNT && bounce == 0) { cnt.phase_lanes[4]++; if ((unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[4]++; }
+                        if (COUNT && (PHILOX ? (sample >> 16) : bounce) == 0) { cnt.phase_lanes[4]++; if ((unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.phase_execs[4]++; }
 #endif
                         const bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
                                                       rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);

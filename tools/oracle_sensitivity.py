@@ -53,7 +53,14 @@ def main():
         images, t0 = {}, time.time()
         for tag, orc in builds.items():
             images[tag], _, cnt = orc.render(*b, 0, frames, accel=True)
-        images["frozen_other_frames"], _, _ = builds["frozen"].render(*b, 1000, frames, accel=True)     # the noise floor
+        # the noise floor: the same build on other frame indices (other seeds), accumulated with the weights of frames 0 .. n-1
+        acc = None
+        for f in range(frames):
+            cur, _ = builds["frozen"].render_frame(*b, 1000 + f, accel=True)
+            if acc is None:
+                acc = np.zeros_like(cur)
+            builds["frozen"].accumulate(acc, cur, f)
+        images["frozen_other_frames"] = acc
         ref = images["frozen"][..., :3]
         row = {"rays": cnt["rays"], "mean_radiance": float(ref.mean()), "seconds": round(time.time() - t0, 1)}
         for tag in ("libm", "fma", "frozen_other_frames"):
