@@ -341,11 +341,10 @@ def main():
             roofline["pmc"] = {k: pmc.get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "td_busy_frac", "wait_any_frac_of_wave_cycles",
                                                         "wait_inst_any_frac_of_wave_cycles", "csrc_sha16", "stale", "source")}
         else:
-            # no PMC pass for this configuration / kernel: the HBM contract figure with the survey's literal bytes stays a bound <= 1
-            roofline.update({"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS, "achieved": hbm["algorithmic_survey_32B_nodes"],
-                             "frac": hbm["algorithmic_survey_frac"],
-                             "definition": "no committed PMC pass for this configuration: SURVEY 8(d) algorithmic bytes (32-B nodes) / launch time; "
-                                           "cache-served, not HBM traffic"})
+            # no PMC pass for this configuration / kernel: the instruction counts are unknown, so no issue fraction is claimed; the HBM contract
+            # figures of SURVEY 8(d) stay under `hbm` (cache-served: they can exceed the HBM peak and are not a roofline fraction)
+            roofline["definition"] = ("no committed rocprofv3 --pmc pass for this configuration: achieved / frac are not claimed (tools/profile.sh + "
+                                      "tools/make_pmc_table.py add one); hbm = SURVEY 8(d) algorithmic bytes / launch time, cache-served")
 
     # ---- latency of one rt_render_frame, camera fixed and camera moved before every frame (untimed extras, rank 0, N = 1)
     latency = None

@@ -236,6 +236,9 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "bvh_top"         device builder: once its bottom-up rounds have left at most this many clusters, the top of the tree is built by the
  *                     host's binned-SAH split search over the clusters' boxes (default 1024: work per ray 1.03x / 0.99x the host tree's on the
  *                     100k- / 1M-triangle workloads, against 1.10x / 1.05x with 0 = clustering up to the root)
+ *   "peer_copies"     rt_multi: 1 = its device-to-device copies (scene fan-out, frame-end gather) go through hipMemcpyPeerAsync even between
+ *                     contexts of one device — the branch a multi-GPU node takes, made runnable on a one-GPU box (default 0: peer API only
+ *                     across devices)
  *   "bvh_radius"      device builder: PLOC search radius of the first rounds, 1..64 (default 8); it doubles once a quarter and again once
  *                     a sixteenth of the clusters is left; a negative value keeps |value| in every round
  *   "rebuild_percent" on-device geometry pipeline: after a refit, rebuild on the device once the summed internal box area exceeds

@@ -115,6 +115,8 @@ struct rt_ctx {
     int opt_bvh_radius = 8;         // device builder: PLOC search radius of the first rounds; doubled once a quarter, again once a sixteenth of
                                     // the clusters is left (negative = that radius in every round).  Work per ray against the host tree at
                                     // 100k / 1M triangles: 8 -> 1.10 / 1.05, 12 -> 1.10 / 1.09, 16 -> 1.10 / 1.17, fixed 16 -> 1.07 / 1.13
+    int opt_peer_copies = 0;        // 1: rt_multi's device-to-device copies take the peer API (hipMemcpyPeerAsync) even between contexts of ONE device
+                                    // — the branch a multi-GPU node takes, runnable on a one-GPU box (tests)
     int opt_bvh_top = 1024;         // device builder: once the bottom-up rounds have left at most this many clusters, the top of the tree is built by the
                                     // host's binned-SAH split search over their boxes (a few hundred KB and about a millisecond; 0 = clustering to the root)
     int opt_rebuild_percent = 200;  // device pipeline: rebuild instead of refit once the internal area exceeds this share of the build's
@@ -548,7 +550,7 @@ template <class T> int clone_buf(rt_ctx* dst, DevBuf<T>& d, const rt_ctx* src, c
 {
     RT_HIP(dst, d.ensure(s.used));
     if (!s.used) return 0;
-    if (dst->device == src->device) RT_HIP(dst, hipMemcpyAsync(d.p, s.p, s.used * sizeof(T), hipMemcpyDeviceToDevice, dst->stream));
+    if (dst->device == src->device && !dst->opt_peer_copies) RT_HIP(dst, hipMemcpyAsync(d.p, s.p, s.used * sizeof(T), hipMemcpyDeviceToDevice, dst->stream));
     else RT_HIP(dst, hipMemcpyPeerAsync(d.p, dst->device, s.p, src->device, s.used * sizeof(T), dst->stream));
     return 0;
 }
@@ -1152,6 +1154,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "compact_nodes")) c->opt_compact_nodes = value ? 1 : 0;
     else if (!std::strcmp(name, "device_bvh")) { if (value < -1 || value > 1) return fail(c, -2, "device_bvh must be -1 (automatic), 0 or 1"); if (value != c->opt_device_bvh) c->scene_dirty = true; c->opt_device_bvh = value; }
     else if (!std::strcmp(name, "bvh_radius")) { if (value == 0 || value < -rtgb::kMaxRadius || value > rtgb::kMaxRadius) return fail(c, -2, "bvh_radius must be in [1,64] (negative: the same radius in every round)"); if (value != c->opt_bvh_radius) c->scene_dirty = true; c->opt_bvh_radius = value; }
+    else if (!std::strcmp(name, "peer_copies")) { if (value != 0 && value != 1) return fail(c, -2, "peer_copies must be 0 or 1"); c->opt_peer_copies = value; }
     else if (!std::strcmp(name, "bvh_top")) { if (value < 0 || value > (1 << 20)) return fail(c, -2, "bvh_top must be in [0,1048576] (0 = the device's clustering builds the whole tree)"); if (value != c->opt_bvh_top) c->scene_dirty = true; c->opt_bvh_top = value; }
     else if (!std::strcmp(name, "rebuild_percent")) { if (value < 0 || value > 100000) return fail(c, -2, "rebuild_percent must be in [0,100000] (0 = never rebuild)"); c->opt_rebuild_percent = value; }
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
@@ -1441,7 +1444,7 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
         rt_ctx* c = m->ctx[i];
         if (c->target_pixels == 0) continue;
         float4* dst = m->d_staging.p + (size_t)(i - 1) * W * max_rows;
-        if (c->device == root->device) M_HIP(m, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, root->stream));
+        if (c->device == root->device && !root->opt_peer_copies) M_HIP(m, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, root->stream));
         else M_HIP(m, hipMemcpyPeerAsync(dst, root->device, c->d_accum.p, c->device, c->target_pixels * sizeof(float4), root->stream));
     }
     for (int i = 0; i < N; ++i) {

@@ -39,6 +39,24 @@ def test_n_contexts_behind_rt_multi_equal_the_undivided_image(rtx, oracle, trace
     assert st["gatherMs"] >= 0.0
 
 
+def test_rt_multi_through_the_peer_copy_api_on_one_device(rtx, oracle):
+    """`peer_copies` = 1 sends the scene fan-out and the frame-end gather through hipMemcpyPeerAsync although every context sits on
+    device 0: the calls, sizes and offsets of the branch a multi-GPU node takes run on the one-GPU box (the xGMI transfer itself does
+    not).  Image and ray count stay the oracle's."""
+    b = rtx.scenes.mesh_test_scene(88, 70).build_buffers()
+    params, spheres, tris, infos = b
+    with rtx.MultiTracer([0] * 4) as mt:
+        mt.set_option("peer_copies", 1)
+        mt.set_params(params)
+        mt.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+        mt.render(0, 3)
+        got = mt.read_accum()
+        st, info = mt.stats(), mt.info()
+    want, _, cnt = oracle.render(*b, 0, 3)
+    assert_bitwise(got, want, "rt_multi x4, peer-copy API")
+    assert st["rays"] == cnt["rays"] and info["bvhBuilds"] == 1
+
+
 def test_rt_multi_builds_the_scene_once_whatever_the_number_of_contexts(rtx, oracle):
     """Eight contexts on device 0: the uploads go to the first context, which builds the scene (one BVH build); the other seven receive
     the built scene device to device and hold no host copy.  A second upload costs one more build; a camera that leaves the padded extent

@@ -13,6 +13,8 @@ profiles)
   tools/profile.sh r03b_config5 --config 5 > $O/prof_r03b_config5.log 2>&1
   tools/profile.sh r03b_config4 --config 4 > $O/prof_r03b_config4.log 2>&1
   tools/profile.sh r03b_config2 --config 2 > $O/prof_r03b_config2.log 2>&1
+  tools/profile.sh r03b_config5_philox --config 5 --rng philox > $O/prof_r03b_config5_philox.log 2>&1
+  tools/profile.sh r03b_config2_philox --config 2 --rng philox > $O/prof_r03b_config2_philox.log 2>&1
   echo profiles done ;;
 bench)
   timeout -k 10 300 python bench.py > $O/bench_r03_config3.json 2> $O/bench_r03_config3.err
@@ -30,6 +32,14 @@ bench)
 validate)
   timeout -k 10 560 python tools/validate_headline.py 16 > $O/validate_headline_r03.txt 2>&1; tail -2 $O/validate_headline_r03.txt
   timeout -k 10 560 python tools/validate_headline.py 16 philox > $O/validate_headline_r03_philox.txt 2>&1; tail -2 $O/validate_headline_r03_philox.txt ;;
+summaries)   # (here, after `profiles` has come back: gpurun_out/prof_r03b* -> profiles/*_summary.{json,md} + profiles/pmc_table.json)
+  python tools/summarize_profile.py r03b k_stream && python tools/make_pmc_table.py r03b 3 1920 1080 64 16
+  python tools/summarize_profile.py r03b_philox k_stream && python tools/make_pmc_table.py r03b_philox 3 1920 1080 64 16 _philox
+  python tools/summarize_profile.py r03b_config5 k_stream && python tools/make_pmc_table.py r03b_config5 5 1920 1080 64 16
+  python tools/summarize_profile.py r03b_config4 k_stream && python tools/make_pmc_table.py r03b_config4 4 3840 2160 64 16
+  python tools/summarize_profile.py r03b_config2 k_trace && python tools/make_pmc_table.py r03b_config2 2 1920 1080 64 16
+  python tools/summarize_profile.py r03b_config5_philox k_stream && python tools/make_pmc_table.py r03b_config5_philox 5 1920 1080 64 16 _philox
+  python tools/summarize_profile.py r03b_config2_philox k_stream && python tools/make_pmc_table.py r03b_config2_philox 2 1920 1080 64 16 _philox ;;
 sensitivity)
   timeout -k 10 900 python tools/oracle_sensitivity.py --size 256 --spp 1024 --out $O/oracle_sensitivity_r03.json > $O/oracle_sensitivity_r03.log 2>&1; tail -2 $O/oracle_sensitivity_r03.log | cut -c1-200 ;;
 esac
