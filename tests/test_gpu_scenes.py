@@ -216,6 +216,24 @@ def test_million_triangle_full_hd_vs_oracle(rtx, oracle, tracer):
     assert rays == cnt["rays"]
 
 
+def test_million_triangle_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
+    """configs[4] exactly as bench.py --config 5 runs it: 1,004,364 triangles, depth of field, 1920x1080, 64 rays per pixel, 8 bounces —
+    every pixel of a whole frame and the ray count (~2.1e8) against the oracle."""
+    m = rtx.scenes.config5()
+    assert (m.numRaysPerPixel, m.maxBounceCount) == (64, 8)
+    rays, cnt = _full_frame_vs_oracle(oracle, tracer, m, "config5 1080p x64 vs oracle", frame=2)
+    assert rays == cnt["rays"] > 150_000_000
+
+
+def test_4k_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
+    """configs[3] exactly as bench.py --config 4 runs it: 3840x2160, 64 rays per pixel, 12 bounces — all 8,294,400 pixels of a frame and
+    the ray count (~9.7e8) against the oracle (its own search tree; the literal loop is covered at 1 ray per pixel above)."""
+    m = rtx.scenes.config4()
+    assert (m.numRaysPerPixel, m.maxBounceCount) == (64, 12)
+    rays, cnt = _full_frame_vs_oracle(oracle, tracer, m, "config4 4K x64 vs oracle", frame=1)
+    assert rays == cnt["rays"] > 800_000_000
+
+
 def test_headline_job_two_frames_accumulated_vs_oracle(rtx, oracle, tracer):
     """A two-frame cut of tools/validate_headline.py: frames 0 and 1 of the headline job (1920x1080, 100,440 triangles, 64 rays per
     pixel, 8 bounces) traced in ONE launch and accumulated — resultTexture and ray count equal the oracle's (~4.9e8 rays)."""
