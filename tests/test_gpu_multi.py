@@ -39,6 +39,22 @@ def test_n_contexts_behind_rt_multi_equal_the_undivided_image(rtx, oracle, trace
     assert st["gatherMs"] >= 0.0
 
 
+def test_rt_multi_in_philox_mode(rtx, oracle):
+    """Three contexts behind one rt_multi in the counter-based mode (keys are global pixel indices, so the bands of every context draw what
+    the undivided image draws): 16 rays per pixel = 16 sample lanes, two frames in one launch, against the oracle twin."""
+    params, spheres, tris, infos = rtx.scenes.mesh_test_scene(90, 52).build_buffers()
+    params = params.copy(); params["rngMode"] = 1; params["numRaysPerPixel"] = 16
+    with rtx.MultiTracer([0] * 3) as mt:
+        mt.set_params(params)
+        mt.upload(spheres=spheres, triangles=tris, meshinfo=infos)
+        mt.render(2, 2)
+        got = mt.read_accum()
+        st = mt.stats()
+    want, _, cnt = oracle.render(params, spheres, tris, infos, 2, 2)
+    assert_bitwise(got, want, "rt_multi x3, Philox mode")
+    assert st["rays"] == cnt["rays"]
+
+
 def test_rt_multi_through_the_peer_copy_api_on_one_device(rtx, oracle):
     """`peer_copies` = 1 sends the scene fan-out and the frame-end gather through hipMemcpyPeerAsync although every context sits on
     device 0: the calls, sizes and offsets of the branch a multi-GPU node takes run on the one-GPU box (the xGMI transfer itself does
