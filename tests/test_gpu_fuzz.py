@@ -125,7 +125,8 @@ def random_scene(rtx, seed):
     return p, sph, tris, infos
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "24"))))   # RTX_FUZZ_SEEDS=400 for a soak run
+_FIRST = int(os.environ.get("RTX_FUZZ_FIRST", "0"))
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(os.environ.get("RTX_FUZZ_SEEDS", "24"))))   # RTX_FUZZ_SEEDS=400 [RTX_FUZZ_FIRST=300] for a soak run
 def test_random_scene_matches_the_oracle(rtx, oracle, tracer, seed):
     b = random_scene(rtx, seed)
     kernel = (0, 1, 3, 1, 2, 1, -1)[seed % 7]
