@@ -225,6 +225,8 @@ def test_million_triangle_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
     assert rays == cnt["rays"] > 150_000_000
 
 
+@pytest.mark.skipif(os.environ.get("RTX_FULL_TESTS", "0") != "1", reason="~9.7e8 oracle rays (about 80 s of the box's host cores): RTX_FULL_TESTS=1 runs it; "
+                    "passed on the final round-3 build (profiles/README.md)")
 def test_4k_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
     """configs[3] exactly as bench.py --config 4 runs it: 3840x2160, 64 rays per pixel, 12 bounces — all 8,294,400 pixels of a frame and
     the ray count (~9.7e8) against the oracle (its own search tree; the literal loop is covered at 1 ray per pixel above)."""
