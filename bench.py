@@ -147,7 +147,10 @@ def main():
 
     dist = None
     dev_index = int(os.environ.get("RTX_BENCH_DEVICE", local_rank))      # rehearsal on a 1-GPU box: all ranks on device 0
-    if world > 1:
+    # RTX_BENCH_FORCE_DIST=1 (tests, one-GPU box): take the N > 1 code path with a process group of ONE rank — RCCL initialised through
+    # torch.distributed, barrier, the frame-end gather and the job report all run for real, on one device
+    force_dist = os.environ.get("RTX_BENCH_FORCE_DIST") == "1" and world == 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
@@ -164,8 +167,8 @@ def main():
         params["rngMode"] = 1
         buffers = (params, spheres, tris, infos)
     W, H = int(params["width"]), int(params["height"])
-    banded = world > 1 and args.decomposition == "bands"
-    sim = args.as_rank_of if world == 1 and args.as_rank_of > 1 else 0
+    banded = (world > 1 or force_dist) and args.decomposition == "bands"
+    sim = args.as_rank_of if world == 1 and args.as_rank_of > 1 and not force_dist else 0
     if sim:
         my_rows = rtx.distributed.band_rows(H, sim, 0)
         row0, nrows, rows = 0, len(my_rows), rtx.distributed.band_rows_padded(H, sim)
@@ -266,7 +269,7 @@ def main():
                 table = {}
             sfx = "_philox" if args.rng == "philox" else ""
             exact = f"config{args.config}_{W}x{H}_{int(params['numRaysPerPixel'])}{sfx}"
-            ent = table.get(exact) if (nrows == H and world == 1) else None
+            ent = table.get(exact) if (nrows == H and world == 1 and not banded) else None
             if ent is None:
                 # the same scene at another resolution / ray count, or a part of the image (a rank of N, --as-rank-of): the per-frame figures
                 # of its committed pass, scaled by rays (the instruction and byte counts per ray of a scene do not depend on the image size)
@@ -348,7 +351,7 @@ def main():
 
     # ---- latency of one rt_render_frame, camera fixed and camera moved before every frame (untimed extras, rank 0, N = 1)
     latency = None
-    if world == 1 and not args.no_latency and not sim:
+    if world == 1 and not args.no_latency and not sim and not force_dist:
         tr.reset_accum()
         tr.render_frame(0)
         t0 = time.perf_counter()
@@ -391,7 +394,7 @@ def main():
         "config": {"workload": f"{names[args.config]}, {W}x{H}, {int(params['numRaysPerPixel'])} rays/pixel/frame "
                                f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, {args.rng.upper()}, FLAT_CHUNKS semantics",
                    "decomposition": (f"{world} ranks, " + ("interleaved 8-row bands" if banded else "contiguous row strips")
-                                     + " + one RCCL gather") if world > 1 else
+                                     + " + one RCCL gather") if (world > 1 or force_dist) else
                                     (f"diagnostic: rank 0 of {sim} (its interleaved bands only, no gather)" if sim else "single GPU"),
                    "rays_per_frame": int(total_rays / max(args.steps, 1)),
                    "triangles": int(len(tris)), "chunks": int(len(infos)), "spheres": int(len(spheres)),

@@ -25,7 +25,7 @@ def gather_image(strip, height: int, dist=None, dst: int = 0):
     """strip: torch tensor [rows_per_rank, W, 4] (rows beyond this rank's nrows are padding).  Returns the assembled
     [height, W, 4] image on rank `dst`, None elsewhere.  One collective."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return strip[:height]
     world, rank = dist.get_world_size(), dist.get_rank()
     bufs = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
@@ -59,7 +59,7 @@ def gather_image_banded(strip, height: int, dist=None, dst: int = 0):
     """strip: torch tensor [band_rows_padded, W, 4] holding this rank's bands back to back.  One gather; rank `dst`
     scatters the gathered rows to their image positions and returns [height, W, 4], the others None."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return strip[:height]
     world, rank = dist.get_world_size(), dist.get_rank()
     bufs = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
@@ -81,7 +81,7 @@ def job_report(dist, comm_device, backend: str, rays: float, wall_s: float, kern
     `world_seen` is the world size the backend itself reports (what RCCL / gloo initialised with), so a line cannot claim more GPUs than
     took part.  dist = None: a single process."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return {"total_rays": rays, "wall_s": wall_s, "world_seen": 1,
                 "per_rank": {"rays": [int(rays)], "kernel_ms": [round(kernel_ms, 3)], "wall_ms": [round(wall_s * 1e3, 3)]},
                 "comm": {"backend": None, "world_seen": 1, "gather_ms": 0.0, "gather_ms_per_rank": [0.0], "bytes": 0}}

@@ -123,3 +123,19 @@ def test_two_gloo_ranks_render_their_bands_on_the_gpu():
            "--master-port", "29517", os.path.join(ROOT, "tests", "gloo_gpu_band_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GLOO_GPU_BANDS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_line_through_rccl_with_a_process_group_of_one():
+    """bench.py's N > 1 code path on the one GPU of the box: RTX_BENCH_FORCE_DIST=1 makes a single rank initialise RCCL through
+    torch.distributed (backend "nccl", device_id), run the barriers, the frame-end gather and the job report's all_gather for real.
+    Not a scaling measurement — it shows that the calls the multi-GPU run makes are valid on this torch / RCCL build."""
+    import json
+    env = dict(os.environ, RTX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "200",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["comm"]["backend"] == "nccl" and line["comm"]["world_seen"] == 1 and line["n_gpus"] == 1
+    assert line["value"] > 0 and line["per_rank"]["rays"][0] > 0 and "RCCL gather" in line["config"]["decomposition"]
