@@ -17,7 +17,7 @@
 
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
-namespace rtk { const void* stream_kernel(bool counting, bool philox, bool compact); }   // rt_stream_kernels.hip
+namespace rtk { const void* stream_kernel(bool counting, bool philox, bool compact, bool triangles); }   // rt_stream_kernels.hip
 // k_pool / k_wave: the two in-wave compaction schedulers of round 1 (measured 40 % / 28 % slower than k_stream, never selected).  They are
 // kept as tested alternatives but only in builds made with -DRT_EXPERIMENTAL_SCHEDULERS (RTX_EXPERIMENTAL=1 python -c "import
 // __graft_entry__ as g; g.build(True)"); the product library does not carry them and refuses kernel = 2 / 3.
@@ -695,7 +695,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
                    : pooled ? (counting ? (const void*)rtk::k_pool<true> : (const void*)rtk::k_pool<false>)
                    : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
 #endif
-                   : stream ? rtk::stream_kernel(counting, philox, compact)       // instantiated in rt_stream_kernels.hip
+                   : stream ? rtk::stream_kernel(counting, philox, compact, c->n_nodes > 0)       // instantiated in rt_stream_kernels.hip
                    : c->n_nodes == 0      // spheres only: the instantiation compiled for six waves per SIMD
                             ? dispatch3(counting, false, false, [](auto C, auto, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, false, 6>; })
                             : dispatch3(counting, false, compact, [](auto C, auto, auto H) { return (const void*)rtk::k_trace<decltype(C)::value, false, decltype(H)::value>; });

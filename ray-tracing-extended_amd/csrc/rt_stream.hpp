@@ -54,15 +54,18 @@ static_assert(alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
 static_assert(offsetof(StreamKernArgs, F) == ((sizeof(DeviceScene) + 7) & ~size_t(7))
               && offsetof(StreamKernArgs, A) == ((offsetof(StreamKernArgs, F) + sizeof(FrameArgs) + 7) & ~size_t(7)), "kernarg layout = struct layout");
 
-template <bool COUNT, bool PHILOX = false, bool H = false>
-// Five waves per SIMD (96 VGPRs: 95 used, no scratch; LDS stack of <= 31 entries per lane so that five workgroups fit a CU): the
+template <bool COUNT, bool PHILOX = false, bool H = false, bool TRI = true>
+// Five waves per SIMD (96 VGPRs: 95 used, no scratch; LDS stack of <= 30 entries per lane so that five workgroups fit a CU): the
 // kernel hides its memory and LDS latencies with resident waves — 3 / 4 / 5 / 6 waves per SIMD gave 10.4 / 12.4 / 12.9 / 11.2 Grays/s
 // on the 100k-triangle workload when this was chosen (11.85 -> 12.75 on the million-triangle one); on the final, spill-free kernel
 // six waves (80 VGPRs, 26 dwords of scratch) measure 14.18 against 14.70 at five.
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES 5
 #endif
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREAM_WAVES, RT_STREAM_WAVES))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
+// TRI = false: the instantiation for scenes without triangles (spheres only) — no traversal state, no burst; 76 / 86 VGPRs (PCG / Philox),
+// compiled for six waves per SIMD: 36.4 -> 39.3 (PCG; k_trace's sphere instantiation stays ahead at 41.7) and 32.6 -> 35.1 Grays/s (Philox)
+// on the sphere workload, eight waves (64 VGPRs, scratch): 37.6 / 29.7.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT_STREAM_WAVES : 6, TRI ? RT_STREAM_WAVES : 6))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -480,15 +483,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                         }
                         live = true;
                         const bool traceable = ray_traceable(o, d, a);      // NaN / zero-direction rays are complete as they stand
-                        if (S.nn > 0 && traceable) {
-                            slab = make_slab<H>(o, d);                                  // RayBoundingBox :179
-                            cur = 0; top = stk0; mode = kModeTrav;
+                        if constexpr (TRI) {
+                            if (S.nn > 0 && traceable) {
+                                slab = make_slab<H>(o, d);                              // RayBoundingBox :179
+                                cur = 0; top = stk0; mode = kModeTrav;
+                            }
                         }
                     }
                 }
             }
         } else {
             // ================================ TRAVERSAL BURST ================================
+            if constexpr (TRI) {
             __builtin_amdgcn_s_setprio(1);
             // while-while over the lanes in flight: node steps until no lane holds an internal node, then every lane
             // tests its whole leaf.  The burst ends when all queries are complete, or as soon as `shade_threshold`
@@ -580,6 +586,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_STREA
                 if (ballot_(mode == kModeTrav) == 0) break;
                 if ((int)__popcll(ballot_(mode == kModeShade)) >= thr) break;
             }
+            }       // (TRI)
         }
     }
     {

@@ -5,9 +5,18 @@
 
 namespace rtk {
 
-// the host-side handle (hipLaunchKernel / occupancy queries) of k_stream<counting, philox, compact nodes>
-const void* stream_kernel(bool counting, bool philox, bool compact)
+// the host-side handle (hipLaunchKernel / occupancy queries) of k_stream<counting, philox, compact nodes, triangles>; a scene without
+// triangles takes the instantiation without traversal code (the node format plays no part in it)
+const void* stream_kernel(bool counting, bool philox, bool compact, bool triangles)
 {
+    if (!triangles) {
+        switch ((counting ? 2 : 0) | (philox ? 1 : 0)) {
+        case 0: return (const void*)k_stream<false, false, false, false>;
+        case 1: return (const void*)k_stream<false, true, false, false>;
+        case 2: return (const void*)k_stream<true, false, false, false>;
+        default: return (const void*)k_stream<true, true, false, false>;
+        }
+    }
     const int v = (counting ? 4 : 0) | (philox ? 2 : 0) | (compact ? 1 : 0);
     switch (v) {
     case 0: return (const void*)k_stream<false, false, false>;

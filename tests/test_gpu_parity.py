@@ -334,6 +334,33 @@ def test_philox_mode_rows_bands_and_depth_of_field(rtx, oracle, tracer):
     assert st["rays"] == cnt["rays"] and st["hits"] == cnt["hits"]
 
 
+@pytest.mark.parametrize("philox", [0, 1])
+def test_stream_kernel_without_triangles(rtx, oracle, tracer, philox):
+    """A scene of spheres only takes k_stream's instantiation without traversal code (six waves per SIMD): 19 frames in one launch
+    (frame-interleaved items / sample lanes), depth of field on, a row strip, and the counting build — image, ray and hit counts are the
+    oracle's in both RNG modes."""
+    m = rtx.scenes.config1(88, 72)
+    m.numRaysPerPixel = 17
+    m.defocusStrength, m.divergeStrength = 40.0, 2.0
+    params, spheres, tris, infos = m.build_buffers()
+    assert len(tris) == 0 and len(spheres) > 0
+    params = params.copy(); params["rngMode"] = philox
+    b = (params, spheres, tris, infos)
+    acc, last = run_gpu(tracer, b, 3, 19, kernel=1)
+    st = tracer.stats()
+    want, want_last, cnt = oracle.render(*b, 3, 19)
+    assert st["lastKernel"] == 1 and st["numBvhNodes"] == 0
+    assert_bitwise(last, want_last, f"spheres only through k_stream, rngMode {philox}: last frame")
+    assert_bitwise(acc, want, f"spheres only through k_stream, rngMode {philox}: accum")
+    assert st["rays"] == cnt["rays"]
+    strip, _ = run_gpu(tracer, b, 3, 19, kernel=1, rows=(13, 40))
+    assert_bitwise(strip, acc[13:53], "row strip")
+    tracer.set_rows(0, 72); tracer.set_params(params); tracer.reset_accum(); tracer.render_counting(3, 19)
+    sc = tracer.stats()
+    assert_bitwise(tracer.read_accum(), acc, "counting build")
+    assert sc["rays"] == cnt["rays"] and sc["hits"] == cnt["hits"] and sc["sphereTests"] == cnt["rays"] * len(spheres)
+
+
 def test_multi_frame_launch_equals_frame_by_frame(rtx, oracle, tracer):
     """rt_render(first, n) traces n frames per k_trace launch (work items = (frame, tile)) and accumulates them in order
     afterwards; the result equals n single-frame launches and the oracle (sun at 200x: the clamped running average is

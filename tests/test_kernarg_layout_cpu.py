@@ -90,4 +90,4 @@ def test_k_stream_kernarg_segment_is_laid_out_like_the_struct_view():
                 pos += a[".size"]
             assert k[".sgpr_spill_count"] == 0, (k[".name"], "k_stream spills SGPRs again: see fresh_kernargs")
             seen += 1
-    assert seen == 8                                       # COUNT x PHILOX x H
+    assert seen == 12                                      # COUNT x PHILOX x H, and COUNT x PHILOX without triangles
