@@ -245,6 +245,8 @@ def main():
     kernel_name = kernel_names.get(chosen, "k_trace<false,false,{H}>").replace("{H}", "true" if compact else "false")
     if len(tris) == 0 and kernel_name.startswith("k_trace"):
         kernel_name = "k_trace<false,false,false,6>"                      # spheres only: the six-waves-per-SIMD instantiation
+    elif len(tris) == 0 and kernel_name.startswith("k_stream"):
+        kernel_name = f"k_stream<false,{'true' if args.rng == 'philox' else 'false'},false,false>"    # ... and k_stream's, without traversal code
     if not args.no_roofline:
         tr.reset_accum()
         tr.render_counting(0, args.steps)
