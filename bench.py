@@ -214,8 +214,10 @@ def main():
     # ---- timed region: exactly K steps + the frame-end gather
     tr.reset_accum()
     barrier()
+    barrier()                                 # (the collective behind the barrier is warm as well when the timed region starts)
     t0 = time.perf_counter()
     tr.render(0, args.steps)
+    render_wall_ms = (time.perf_counter() - t0) * 1e3
     gather_ms = 0.0
     if dist is not None:
         tg = time.perf_counter()
@@ -224,12 +226,17 @@ def main():
         if comm_dev != "cpu":
             torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+    tb = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    closing_barrier_ms = (time.perf_counter() - tb) * 1e3
     st = tr.stats()
     job = rtx.distributed.job_report(dist, comm_dev, args.backend if dist is not None else None, float(st["rays"]), dt, st["totalKernelMs"],
                                      gather_ms, strip.numel() * 4)
     total_rays, wall = job["total_rays"], job["wall_s"]
+    if dist is not None:
+        job["comm"]["closing_barrier_ms_rank0"] = round(closing_barrier_ms, 3)     # rank 0's wait in the barrier that ends the timed region
+        job["comm"]["render_wall_ms_rank0"] = round(render_wall_ms, 3)             # rank 0: rt_render of the K steps, call to return
     if job["world_seen"] != world:
         raise SystemExit(f"the {args.backend} process group has {job['world_seen']} ranks, WORLD_SIZE says {world}")
     kernel_ms_rank0 = st["totalKernelMs"]
