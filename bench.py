@@ -245,7 +245,7 @@ def main():
     # ---- roofline (rank 0's strip): counting build of the same kernel over the same K frames, untimed
     roofline = None
     kernel_names = ({1: "k_stream<false,true,{H}>"} if args.rng == "philox" else
-                    {0: "k_trace<false,false,{H}>", 1: "k_stream<false,false,{H}>", 2: "k_pool<false>", 3: "k_wave<false>"})
+                    {0: "k_trace<false,false,{H}>", 1: "k_stream<false,false,{H}>"})
     chosen = st.get("lastKernel", -1)                    # the kernel that ran the timed launches
     opts = dict(kv.split("=") for kv in args.opt)
     compact = int(opts.get("compact_nodes", 1)) != 0

@@ -151,7 +151,7 @@ typedef struct rt_stats {
     double   lastDisplayMs;             /* HIP-event time of the last linear -> sRGB8 display kernel     */
     int32_t  lastFramesPerLaunch;       /* frames traced per k_trace launch in the last rt_render (1 = frame by frame) */
     int32_t  autoKernel;                /* kernel the automatic choice picked for single-frame launches (-1 = not decided yet / not automatic) */
-    int32_t  lastKernel;                /* kernel that ran the last launch: 0 k_trace, 1 k_stream, 2 k_pool, 3 k_wave, 4 flat twin */
+    int32_t  lastKernel;                /* kernel that ran the last launch: 0 k_trace, 1 k_stream, 4 flat twin */
     int32_t  lastFramesInterleaved;     /* k_stream: frames interleaved in a wave by the last launch (1, 4 or 16)        */
     double   lastBvhBuildMs;            /* last BVH build: HIP-event time of the device builder (sort + PLOC + collapse + records), */
                                         /* or host wall time of the binned-SAH builder                                   */
@@ -205,9 +205,7 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
 /* Tuning knobs; the image never depends on them (tested bitwise).
  *   "kernel"          -1 = automatic (default): the first frames after a scene / camera change time k_trace and k_stream on
  *                     ordinary frames of the render and the faster one takes the rest; 0 = tile-per-wave megakernel k_trace,
- *                     1 = k_stream (resumable traversal, stragglers deferred; the only kernel of the Philox mode); 2 = k_pool, 3 = k_wave:
- *                     the two in-wave compaction schedulers of round 1 (-40 % / -28 %), compiled only into builds made with
- *                     -DRT_EXPERIMENTAL_SCHEDULERS — the product library answers them with an error
+ *                     1 = k_stream (resumable traversal, stragglers deferred; the only kernel of the Philox mode)
  *   "max_leaf"        triangles per BVH leaf, 1..4 (default 2)
  *   "bvh_bins", "bvh_cost_exp", "bvh_reinsert"   BVH builder: SAH bins per axis (32); exponent, in percent, of the triangle
  *                     count in the SAH's subtree-cost model (100); passes of insertion-based optimisation of the binary tree (0:
@@ -245,9 +243,6 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     this percentage of its value right after the last build (default 200; 0 = never)
  *   "compact_nodes"   k_trace / k_stream: 1 = traverse the f16 form of the BVH nodes (5 loads per node visit, default), 0 = the
  *                     f32 form (7 loads)
- *   "pool_stack", "trav_min_lanes"   k_pool: LDS stack entries per lane; in-flight lanes below which TRAVERSE is left
- *   "refill_min", "wave_trav_min", "wave_node_min"   k_wave: idle lanes that trigger a refill from the pending list (16);
- *                     in-flight lanes below which TRAVERSE is left once the list is dry (24); node-loop hand-over (24)
  *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);
 

@@ -18,20 +18,6 @@
 #include "rt_kernels.hpp"
 #include "rt_stream.hpp"
 namespace rtk { const void* stream_kernel(bool counting, bool philox, bool compact, bool triangles); }   // rt_stream_kernels.hip
-// k_pool / k_wave: the two in-wave compaction schedulers of round 1 (measured 40 % / 28 % slower than k_stream, never selected).  They are
-// kept as tested alternatives but only in builds made with -DRT_EXPERIMENTAL_SCHEDULERS (RTX_EXPERIMENTAL=1 python -c "import
-// __graft_entry__ as g; g.build(True)"); the product library does not carry them and refuses kernel = 2 / 3.
-#ifdef RT_EXPERIMENTAL_SCHEDULERS
-#include "rt_pool.hpp"
-#include "rt_wave.hpp"
-#define RT_EXPERIMENTAL 1
-#else
-#define RT_EXPERIMENTAL 0
-namespace rtk { struct PoolArgs { unsigned int total_pixels; int trav_min_lanes, lds_stack_cap; unsigned int gstack_stride; uint32_t* gstack; };
-                struct WaveArgs { uint32_t* state; int refill_min, trav_min_lanes, node_min; unsigned int total_pixels; };
-                namespace pool { constexpr int kMaxSamples = 0; inline int wave_dwords(int) { return 0; } }
-                namespace wv { constexpr int kMaxSamples = 0, kMaxBounce = 0, kMaxFrames = 1; inline size_t wave_lds_bytes(int) { return 0; } inline size_t wave_state_dwords() { return 0; } } }
-#endif
 #include "rt_geom.hpp"
 #include "rt_bvh_gpu.hpp"
 
@@ -121,7 +107,7 @@ struct rt_ctx {
                                     // host's binned-SAH split search over their boxes (a few hundred KB and about a millisecond; 0 = clustering to the root)
     int opt_rebuild_percent = 200;  // device pipeline: rebuild instead of refit once the internal area exceeds this share of the build's
     int n_cu = 0;
-    int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream, 2: k_pool
+    int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream
     int auto_choice = -1; double auto_ms[2] = { -1.0, -1.0 };
     unsigned variants_launched = 0;     // kernel variants that have run at least once in this context (automatic choice: see launch_frames)
     int opt_shade_threshold = 48;
@@ -147,14 +133,8 @@ struct rt_ctx {
     int opt_stream_stack = 30;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory.  30 entries + the groups' item
                                     // tables = 31,744 B per workgroup: five workgroups per CU (32,768 B already makes it four: measured -11 %)
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
-    int opt_pool_stack = 10;        // k_pool: stack entries per lane kept in LDS (deeper entries spill to global memory)
-    int opt_trav_min_lanes = 32;    // k_pool: leave TRAVERSE below this many in-flight lanes
     DevBuf<uint32_t> d_gstack;
     DevBuf<float> d_park;              // k_stream, Philox mode: parked sub-stream sums
-    DevBuf<uint32_t> d_wave_state;     // k_wave: path state of every wave's pixel slots
-    int opt_refill_min = 16;        // k_wave: idle lanes that trigger a refill from the pending list
-    int opt_wave_node_min = 24;     // k_wave: its node loop hands over to the leaves below this many descending lanes
-    int opt_wave_trav_min = 24;     // k_wave: leave TRAVERSE below this many in-flight lanes once the pending list is dry
     rt_stats stats{};
 };
 
@@ -613,7 +593,7 @@ template <class Fn> const void* dispatch3(bool a, bool b, bool c3, Fn f)
     return a ? lvl2(std::true_type{}) : lvl2(std::false_type{});
 }
 
-// One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream, 2 k_pool, 3 k_wave).
+// One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream).
 int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int kernel)
 {
     if (!c) return -1;
@@ -664,13 +644,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         return fail(c, -7, "the Philox mode takes at most 65000 rays per pixel per frame and 65000 bounces (16-bit sample and bounce counters)");
     const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1        // PCG or Philox instantiation
                         && c->target_w <= 65535 && c->target_rows <= 65535;                          // (16-bit pixel coordinates in k_stream's item tables)
-    const bool pooled = RT_EXPERIMENTAL && !philox && kernel == 2 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
-                        && c->params.numRaysPerPixel <= rtk::pool::kMaxSamples && c->params.maxBounceCount < 65535;
-    const bool waved = RT_EXPERIMENTAL && !philox && kernel == 3 && var != Variant::Flat && c->params.numRaysPerPixel >= 1
-                       && c->params.numRaysPerPixel <= rtk::wv::kMaxSamples && c->params.maxBounceCount <= rtk::wv::kMaxBounce
-                       && c->target_w <= 65535 && c->target_rows <= 65535;
-    F.stack_cap = std::max(1, c->bvh.maxStack) + (stream || waved ? 3 : 0);    // the branch-free push writes up to 3 slots past the top
-    const bool tile_kernel = !stream && !pooled && !waved && var != Variant::Flat;   // k_trace, PCG or Philox
+    F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // the branch-free push writes up to 3 slots past the top
+    const bool tile_kernel = !stream && var != Variant::Flat;   // k_trace, PCG or Philox
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     if (tile_kernel) F.stack_cap = std::min(F.stack_cap, 64);        // a very deep tree spills past 64 entries instead of overflowing the LDS
     // k_stream: at most opt_stream_stack entries per lane in LDS (30 = five workgroups per CU); a deeper worst case spills
@@ -681,20 +656,13 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
     F.tile_counter = c->d_tile_counter; F.counters = c->d_counters;
 
-    const int pool_cap = std::max(1, std::min(c->opt_pool_stack, std::max(1, c->bvh.maxStack)));
     const size_t lds = var == Variant::Flat ? 0
-                     : pooled ? (size_t)rtk::pool::wave_dwords(pool_cap) * sizeof(uint32_t) * rtk::kWavesPerBlock
-                     : waved ? rtk::wv::wave_lds_bytes(F.stack_cap) * rtk::kWavesPerBlock
                               : (size_t)F.stack_cap * 64 * sizeof(uint32_t) * rtk::kWavesPerBlock
                                 + (stream ? (size_t)rtk::kGroupMax * sizeof(uint2) * rtk::kWavesPerBlock : 0);     // k_stream: + the groups' item tables
     if (lds > 160 * 1024) return fail(c, -7, "BVH needs a %d-entry traversal stack: exceeds the 160 KiB LDS", F.stack_cap);
     const bool counting = var == Variant::Counting;
-    const bool compact = c->opt_compact_nodes != 0;            // k_trace / k_stream only; k_pool, k_wave and the flat twin read the f32 nodes
+    const bool compact = c->opt_compact_nodes != 0;            // k_trace / k_stream; the flat twin reads neither
     const void* fn = var == Variant::Flat ? (const void*)rtk::k_trace<false, true>
-#if RT_EXPERIMENTAL
-                   : pooled ? (counting ? (const void*)rtk::k_pool<true> : (const void*)rtk::k_pool<false>)
-                   : waved ? (counting ? (const void*)rtk::k_wave<true> : (const void*)rtk::k_wave<false>)
-#endif
                    : stream ? rtk::stream_kernel(counting, philox, compact, c->n_nodes > 0)       // instantiated in rt_stream_kernels.hip
                    : c->n_nodes == 0      // spheres only: the instantiation compiled for six waves per SIMD
                             ? dispatch3(counting, false, false, [](auto C, auto, auto) { return (const void*)rtk::k_trace<decltype(C)::value, false, false, 6>; })
@@ -704,17 +672,12 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::kBlock, lds));
     if (per_cu < 1) return fail(c, -7, "kernel does not fit a CU (LDS %zu B)", lds);
     const int ntiles = F.tiles_x * F.tiles_y;
-    // k_pool waves own 128 pixel slots each: two tiles' worth
-    // ... and k_wave waves 256: four tiles' worth (of any frame of the launch)
-    const int frames_hint = waved ? std::max(1, std::min(n_frames, 8)) : 1;
     // work items of a multi-frame launch = tiles x frames: a thin strip (one rank of eight: 4,080 tiles) still fills every resident wave
     // Philox mode: S = 16 / 4 / 1 sample lanes per pixel (the estimator's sub-streams, include/rt.h RT_RNG_PHILOX)
     const int sample_lanes_log2 = !philox ? 0 : c->params.numRaysPerPixel >= 16 ? 4 : c->params.numRaysPerPixel >= 4 ? 2 : 0;
     const bool stream_sync = stream && (c->opt_tile_sync || philox);       // k_stream taking whole work items (the Philox instantiation always does)
     const size_t frames_in_queue = ((stream_sync && c->opt_frame_batch != 1) ? (size_t)std::max(1, std::min(n_frames, 64)) : 1) << sample_lanes_log2;
-    const int want = pooled ? (ntiles + 2 * rtk::kWavesPerBlock - 1) / (2 * rtk::kWavesPerBlock)
-                   : waved ? (int)(((size_t)ntiles * frames_hint + 4 * rtk::kWavesPerBlock - 1) / (4 * rtk::kWavesPerBlock))
-                            : (int)std::min<size_t>(((size_t)ntiles * frames_in_queue + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock, (size_t)1 << 20);
+    const int want = (int)std::min<size_t>(((size_t)ntiles * frames_in_queue + rtk::kWavesPerBlock - 1) / rtk::kWavesPerBlock, (size_t)1 << 20);
     if (c->opt_blocks_per_cu > 0) per_cu = std::min(per_cu, c->opt_blocks_per_cu);
     const int grid = std::max(1, std::min(want, per_cu * c->n_cu));
     rtk::StreamArgs A{};
@@ -725,57 +688,41 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     A.tiles_per_fetch = std::max(1, std::min(rtk::kGroupMax, c->opt_tiles_per_fetch));
     A.guide_div = 1;
     A.node_min = std::max(1, std::min(64, c->opt_node_min));
-    rtk::PoolArgs PA{};
-    PA.total_pixels = A.total_pixels;
-    PA.trav_min_lanes = std::max(1, std::min(64, c->opt_trav_min_lanes));
-    PA.lds_stack_cap = pool_cap;
-    PA.gstack_stride = (unsigned int)grid * rtk::kBlock;
-    rtk::WaveArgs WA{};
-    if (waved) {
-        RT_HIP(c, c->d_wave_state.ensure((size_t)grid * rtk::kWavesPerBlock * rtk::wv::wave_state_dwords()));
-        WA.state = c->d_wave_state.p;
-        WA.refill_min = std::max(1, std::min(64, c->opt_refill_min));
-        WA.trav_min_lanes = std::max(1, std::min(64, c->opt_wave_trav_min));
-        WA.node_min = std::max(1, std::min(64, c->opt_wave_node_min));
-    }
+    const unsigned int gstack_stride = (unsigned int)grid * rtk::kBlock;
     if (philox) {      // where the lanes park their sub-stream sums until the wave's group of items is done: [wave][item of the group][3][64]
         RT_HIP(c, c->d_park.ensure((size_t)grid * rtk::kWavesPerBlock * (size_t)A.tiles_per_fetch * 192));
         F.park = c->d_park.p;
     }
     if (stream_spill) {
-        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack + 3 - F.stack_cap) * PA.gstack_stride));
-        F.gstack = c->d_gstack.p; F.gstack_stride = PA.gstack_stride;
+        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack + 3 - F.stack_cap) * gstack_stride));
+        F.gstack = c->d_gstack.p; F.gstack_stride = gstack_stride;
     }
     if (tile_kernel && c->bvh.maxStack > F.stack_cap) {
-        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - F.stack_cap) * PA.gstack_stride));
-        F.gstack = c->d_gstack.p; F.gstack_stride = PA.gstack_stride;
-    }
-    if (pooled && c->bvh.maxStack > pool_cap) {
-        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - pool_cap) * PA.gstack_stride));
-        PA.gstack = c->d_gstack.p;
+        RT_HIP(c, c->d_gstack.ensure((size_t)(c->bvh.maxStack - F.stack_cap) * gstack_stride));
+        F.gstack = c->d_gstack.p; F.gstack_stride = gstack_stride;
     }
 
     // k_trace can trace several frames per launch (work items = (frame, tile)): the persistent waves then balance over
     // frames as well — what matters when a rank's strip has about as many tiles as the chip has wave slots.
     int batch = 1;
     const bool stream_tiles = stream_sync;                       // k_stream taking whole tiles: same (frame, tile) items as k_trace
-    if ((tile_kernel || stream_tiles || waved) && n_frames > 1 && c->opt_frame_batch != 1) {
+    if ((tile_kernel || stream_tiles) && n_frames > 1 && c->opt_frame_batch != 1) {
         const size_t budget = (size_t)4 << 30;                                  // <= 4 GiB of per-frame outputs (16 frames at 3840x2160)
         const size_t per_frame = c->target_pixels * sizeof(float4);
         batch = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, budget / per_frame));
         if (c->opt_frame_batch > 1) batch = std::min(batch, c->opt_frame_batch);
-        batch = std::min(batch, waved ? rtk::wv::kMaxFrames : 256);
+        batch = std::min(batch, 256);
         if (batch > 1) RT_HIP(c, c->d_batch.ensure((size_t)batch * c->target_pixels));
     }
     // LPT scheduling of the persistent waves: a launch records every tile's cost; the next ones hand tiles out costliest
     // first, so the end of a launch is filled with cheap tiles instead of waiting for a few expensive ones.
-    const bool lpt = (tile_kernel || stream_sync || waved) && c->opt_tile_lpt && ntiles > 1;
+    const bool lpt = (tile_kernel || stream_sync) && c->opt_tile_lpt && ntiles > 1;
     c->lpt_active = lpt;
     bool record_costs = false;
     if (lpt) {
         if (c->tile_order_n != ntiles) { c->tile_order_valid = false; c->tile_order_n = ntiles; }
         RT_HIP(c, c->d_tile_cost.ensure(ntiles)); RT_HIP(c, c->d_tile_order.ensure(ntiles));
-        if ((!c->tile_order_valid || c->tile_order_stale) && !waved) {       // k_wave mixes tiles in a wave: it uses an order, it cannot measure one
+        if (!c->tile_order_valid || c->tile_order_stale) {
             record_costs = true;
             RT_HIP(c, hipMemsetAsync(c->d_tile_cost.p, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
         }
@@ -807,9 +754,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         F.frames_in_launch = nb; F.frame_stride = (unsigned int)c->target_pixels;
         F.out_frame = nb > 1 ? c->d_batch.p : c->d_frame.p;
         RT_HIP(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
-        WA.total_pixels = (unsigned int)ntiles * 64u * (unsigned int)nb;
         {
-            void* args[3] = { (void*)&S, (void*)&F, waved ? (void*)&WA : pooled ? (void*)&PA : (void*)&A };    // k_trace takes (S, F) only
+            void* args[3] = { (void*)&S, (void*)&F, (void*)&A };    // k_trace takes (S, F) only
             RT_HIP(c, hipLaunchKernel(fn, dim3(grid), dim3(rtk::kBlock), args, lds, c->stream));
         }
         RT_HIP(c, hipGetLastError());
@@ -822,7 +768,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         i += nb;
     }
     c->stats.lastFramesPerLaunch = batch;
-    c->stats.lastKernel = var == Variant::Flat ? 4 : waved ? 3 : pooled ? 2 : stream ? 1 : 0;
+    c->stats.lastKernel = var == Variant::Flat ? 4 : stream ? 1 : 0;
     c->stats.lastFramesInterleaved = stream ? (philox ? 1 : A.n16 ? 16 : A.n4 ? 4 : 1) : 1;
     c->stats.lastSampleLanes = philox ? 1 << sample_lanes_log2 : 1;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -869,21 +815,6 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
                           && c->params.numRaysPerPixel >= 1 && c->params.rngMode != RT_RNG_PHILOX;   // (Philox: always k_stream)
     if (!eligible) {
         const int kernel = c->opt_kernel < 0 ? 0 : c->opt_kernel;
-        // k_wave hands tiles out costliest first but cannot measure a tile's cost itself: k_trace traces the first frame
-        // after a scene / target change and records the costs (an ordinary frame of the render, nothing is traced twice)
-        if (kernel == 3 && var != Variant::Flat && c->opt_tile_lpt && n_frames > 1 && c->have_params
-            && (c->scene_dirty || !c->tile_order_valid || c->tile_order_stale)) {
-            int r = launch_frames_k(c, first_frame, 1, var, 0);
-            if (r) return r;
-            const rt_stats a = c->stats;
-            r = launch_frames_k(c, first_frame + 1, n_frames - 1, var, kernel);
-            if (r) return r;
-            c->stats.rays += a.rays; c->stats.sphereTests += a.sphereTests; c->stats.nodeVisits += a.nodeVisits;
-            c->stats.triTests += a.triTests; c->stats.hits += a.hits;
-            for (int k = 0; k < 5; ++k) { c->stats.phaseLanes[k] += a.phaseLanes[k]; c->stats.phaseExecs[k] += a.phaseExecs[k]; }
-            c->stats.lastKernelMs += a.lastKernelMs;
-            return 0;
-        }
         return launch_frames_k(c, first_frame, n_frames, var, kernel);
     }
     // (with the costliest-first order switched off, or a single tile, there is no order to wait for)
@@ -1006,7 +937,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_park.release(); c->d_wave_state.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
+    c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_park.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1127,15 +1058,9 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     if (!c) return -1;
     if (!name) return fail(c, -2, "null option name");
     if (!std::strcmp(name, "kernel")) {
-        if (value < -1 || value > 3) return fail(c, -2, "kernel must be -1 (auto), 0, 1, 2 or 3");
-        if (!RT_EXPERIMENTAL && value >= 2) return fail(c, -8, "kernel %d (k_pool / k_wave) is not compiled into this build of the library (RT_EXPERIMENTAL_SCHEDULERS)", value);
+        if (value < -1 || value > 1) return fail(c, -2, "kernel must be -1 (auto), 0 (k_trace) or 1 (k_stream)");
         c->opt_kernel = value;
     }
-    else if (!std::strcmp(name, "pool_stack")) { if (value < 1 || value > 64) return fail(c, -2, "pool_stack must be in [1,64]"); c->opt_pool_stack = value; }
-    else if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) return fail(c, -2, "refill_min must be in [1,64]"); c->opt_refill_min = value; }
-    else if (!std::strcmp(name, "wave_node_min")) { if (value < 1 || value > 64) return fail(c, -2, "wave_node_min must be in [1,64]"); c->opt_wave_node_min = value; }
-    else if (!std::strcmp(name, "wave_trav_min")) { if (value < 1 || value > 64) return fail(c, -2, "wave_trav_min must be in [1,64]"); c->opt_wave_trav_min = value; }
-    else if (!std::strcmp(name, "trav_min_lanes")) { if (value < 1 || value > 64) return fail(c, -2, "trav_min_lanes must be in [1,64]"); c->opt_trav_min_lanes = value; }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
     else if (!std::strcmp(name, "stream_stack")) { if (value < 4 || value > 128) return fail(c, -2, "stream_stack must be in [4,128]"); c->opt_stream_stack = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }

@@ -1,21 +1,18 @@
 """Edge cases the reference's semantics define: empty and ragged inputs, zero bounces, special material
 flags, axis-aligned rays (exact zero direction components -> infinite reciprocals), degenerate primitives, depth of field.
-Every case: GPU (all three kernels where cheap) == oracle, bit for bit."""
+Every case: GPU (both kernels) == oracle, bit for bit."""
 import numpy as np
 import pytest
 
-from test_gpu_parity import assert_bitwise, kernels, run_gpu
+from test_gpu_parity import assert_bitwise, run_gpu
 
 pytestmark = pytest.mark.gpu
 
 
-kernels_ = kernels
-
-
-def check(rtx, oracle, tracer, mgr, frames=2, first=0, kernels=(0, 1, 2, 3), what=""):
+def check(rtx, oracle, tracer, mgr, frames=2, first=0, kernels=(0, 1), what=""):
     b = mgr.build_buffers()
     want, want_last, _ = oracle.render(*b, first, frames)
-    for k in kernels_(tracer, kernels):
+    for k in kernels:
         acc, last = run_gpu(tracer, b, first, frames, kernel=k)
         assert_bitwise(last, want_last, f"{what} kernel {k} last frame")
         assert_bitwise(acc, want, f"{what} kernel {k} accum")
@@ -61,7 +58,7 @@ def test_ragged_chunks_zero_triangle_chunk_and_unreferenced_triangles(rtx, oracl
     infos["numTriangles"][5] -= 3                      # the last 3 triangles of that chunk become unreachable
     b = (params, spheres, tris, infos)
     want, want_last, _ = oracle.render(*b, 0, 1)
-    for k in kernels(tracer, (0, 1, 2)):
+    for k in (0, 1):
         acc, last = run_gpu(tracer, b, 0, 1, kernel=k)
         assert_bitwise(last, want_last, f"ragged chunks kernel {k}")
 
@@ -180,7 +177,7 @@ def test_zero_normals_make_nan_rays_that_hit_nothing(rtx, oracle, tracer):
     tris["normalA"][::2] = 0; tris["normalB"][::2] = 0; tris["normalC"][::2] = 0
     b[2] = tris
     want, want_last, _ = oracle.render(*b, 1, 2)
-    for k in kernels(tracer, (0, 1, 2, 3)):
+    for k in (0, 1):
         acc, last = run_gpu(tracer, tuple(b), 1, 2, kernel=k)
         assert_bitwise(last, want_last, f"NaN rays, kernel {k}, last frame")
         assert_bitwise(acc, want, f"NaN rays, kernel {k}, accum")
@@ -217,7 +214,7 @@ def test_nan_and_zero_direction_rays_do_not_walk_the_tree(rtx, oracle, tracer):
         tris[f] = 0.0                                     # every triangle hit makes a NaN bounce ray
     b = (params, spheres, tris, infos)
     want, want_last, cnt = oracle.render(*b, 0, 2)
-    for kernel in kernels(tracer, (0, 1, 2, 3)):
+    for kernel in (0, 1):
         tracer.set_option("kernel", kernel)
         tracer.set_params(params); tracer.upload(spheres=spheres, triangles=tris, meshinfo=infos)
         tracer.set_rows(0, int(params["height"]))

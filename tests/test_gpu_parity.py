@@ -18,26 +18,7 @@ def assert_bitwise(got, want, what):
                              f"gpu {got[y, x]} oracle {want[y, x]}")
 
 
-_EXPERIMENTAL = {}
-
-
-def kernels(tracer, wanted):
-    """`wanted` without the schedulers this build of the library does not carry: k_pool (2) and k_wave (3) are compiled only with
-    -DRT_EXPERIMENTAL_SCHEDULERS (RTX_EXPERIMENTAL=1 at build time); the product library refuses them."""
-    if "have" not in _EXPERIMENTAL:
-        try:
-            tracer.set_option("kernel", 2)
-            _EXPERIMENTAL["have"] = True
-        except RuntimeError as e:
-            assert "not compiled into this build" in str(e)
-            _EXPERIMENTAL["have"] = False
-        tracer.set_option("kernel", 0)
-    return tuple(k for k in wanted if k < 2 or _EXPERIMENTAL["have"])
-
-
 def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=0, shade_threshold=48, tile_sync=1):
-    if kernel >= 2 and not kernels(tracer, (kernel,)):
-        pytest.skip("k_pool / k_wave are not compiled into this build of the library (RTX_EXPERIMENTAL=1 to build them)")
     params, spheres, tris, infos = buffers
     p = params.copy()
     if mode is not None:
@@ -54,7 +35,7 @@ def run_gpu(tracer, buffers, first, n, mode=None, rows=None, kernel=0, shade_thr
     return tracer.read_accum(), tracer.read_last_frame()
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [0, 1])
 def test_config1_spheres_bitwise(rtx, oracle, tracer, kernel):
     """configs[0]: 16 spheres, 256x256, 4 rays, 3 bounces — full image, frame 0."""
     b = rtx.scenes.config1().build_buffers()
@@ -73,7 +54,7 @@ def test_config1_accumulate_three_frames(rtx, oracle, tracer):
     assert want_acc.max() <= 1.0
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_mesh_scene_bvh_bitwise(rtx, oracle, tracer, mode, kernel):
     """Triangles through the BVH == the reference's flat chunk loop (mode 0) / brute force (mode 1), for both
@@ -152,23 +133,6 @@ def test_schedule_knobs_do_not_change_the_image(rtx, tracer, threshold, tile_syn
     assert_bitwise(got_last, ref_last, f"stream(threshold={threshold}) vs tile kernel, last frame")
 
 
-@pytest.mark.parametrize("trav_min,pool_stack", [(1, 10), (32, 2), (64, 10), (40, 64)])
-def test_pool_kernel_knobs_do_not_change_the_image(rtx, tracer, trav_min, pool_stack):
-    """Wave-pool kernel (ballot/prefix-sum compaction) == tile-per-wave kernel for any suspend threshold and with the
-    traversal stack forced to spill to global memory (pool_stack=2), odd image size."""
-    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
-    ref, ref_last = run_gpu(tracer, b, 2, 2, kernel=0)
-    tracer.set_option("trav_min_lanes", trav_min)
-    tracer.set_option("pool_stack", pool_stack)
-    try:
-        got, got_last = run_gpu(tracer, b, 2, 2, kernel=2)
-    finally:
-        tracer.set_option("trav_min_lanes", 32)
-        tracer.set_option("pool_stack", 10)
-    assert_bitwise(got_last, ref_last, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, last frame")
-    assert_bitwise(got, ref, f"pool(trav_min={trav_min}, stack={pool_stack}) vs tile kernel, accum")
-
-
 @pytest.mark.parametrize("stream_stack", [4, 7, 12])
 def test_stream_stack_spill_does_not_change_the_image(rtx, tracer, stream_stack):
     """k_stream with only a few traversal-stack entries per lane in LDS (the rest spills to global memory) == tile kernel:
@@ -188,28 +152,7 @@ def test_stream_stack_spill_does_not_change_the_image(rtx, tracer, stream_stack)
     assert rays == rays_ref
 
 
-@pytest.mark.parametrize("refill_min,trav_min,node_min", [(1, 1, 1), (64, 64, 64), (16, 24, 24), (8, 48, 4)])
-def test_wave_kernel_knobs_do_not_change_the_image(rtx, tracer, refill_min, trav_min, node_min):
-    """k_wave (256 pixel slots per wave, path state in global memory, phases on compacted slot lists) == tile-per-wave
-    kernel for any refill / suspend / node-loop threshold; odd image size, three frames in one launch, and the ray count."""
-    b = rtx.scenes.mesh_test_scene(93, 61).build_buffers()
-    ref, ref_last = run_gpu(tracer, b, 2, 3, kernel=0)
-    rays_ref = tracer.stats()["rays"]
-    for k, v in (("refill_min", refill_min), ("wave_trav_min", trav_min), ("wave_node_min", node_min), ("tile_lpt", 0)):
-        tracer.set_option(k, v)
-    try:
-        got, got_last = run_gpu(tracer, b, 2, 3, kernel=3)
-        rays = tracer.stats()["rays"]
-    finally:
-        for k, v in (("refill_min", 16), ("wave_trav_min", 24), ("wave_node_min", 24), ("tile_lpt", 1)):
-            tracer.set_option(k, v)
-    what = f"wave(refill={refill_min}, trav_min={trav_min}, node_min={node_min})"
-    assert_bitwise(got_last, ref_last, what + " vs tile kernel, last frame")
-    assert_bitwise(got, ref, what + " vs tile kernel, accum")
-    assert rays == rays_ref
-
-
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [0, 1])
 def test_interleaved_bands_are_decomposition_invariant(rtx, tracer, kernel):
     """8-row bands dealt round-robin to 3 'ranks' reassemble to the undivided image (61 rows: partial last band)."""
     b = rtx.scenes.mesh_test_scene(80, 61).build_buffers()
@@ -272,11 +215,11 @@ def test_philox_mode_bitwise_vs_oracle(rtx, oracle, tracer, scene, rays):
 
 
 def test_philox_mode_is_served_by_k_stream_whatever_kernel_is_asked_for(rtx, oracle, tracer):
-    """kernel = 0 / 2 / 3 / automatic in Philox mode all run k_stream's Philox instantiation (the only one with the estimator's
+    """kernel = 0 / automatic in Philox mode both run k_stream's Philox instantiation (the only one with the estimator's
     tree); zero rays per pixel draws nothing and goes to k_trace (0 / 0 = NaN in both modes, as in the oracle)."""
     b = _philox(rtx.scenes.mesh_test_scene(48, 40).build_buffers(), 6)
     want, want_last, _ = oracle.render(*b, 0, 3)
-    for kernel in kernels(tracer, (0, 2, 3, -1)):
+    for kernel in (0, -1):
         acc, last = run_gpu(tracer, b, 0, 3, kernel=kernel)
         assert tracer.stats()["lastKernel"] == 1
         assert_bitwise(acc, want, f"philox, kernel option {kernel}")
