@@ -7,6 +7,7 @@ on the ~100k-triangle scene (configs[2]).  A *step* is one frame = one trace+acc
 (RayTracing.shader:256), counted by the kernel itself.
 
     python bench.py --gpus 1 --steps 16 --warmup 1
+    python bench.py --gpus N --steps K --warmup W        (starts the N ranks itself, as a child process, and relays their one line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -72,7 +73,67 @@ def parse():
     ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
                     help="diagnostic on one GPU: render only what rank 0 of N ranks would (bands 0, N, 2N, ...): the compute side of the N-GPU "
                          "strong-scaling run without the gather; the printed value is this rank's own rate, not a job rate")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="no device, no rendering: the ranks only rendezvous, gather analytically filled strips and build the job report — "
+                         "what a box without a GPU can check of the N > 1 launch path (value = 0, data = 'none')")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N ranks with torch.distributed.run as a CHILD
+    process — before this process has imported torch or touched a device — relay rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)        # (stderr goes straight through)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode == 0 and len(lines) != 1:
+        sys.stdout.write(r.stdout)
+        raise SystemExit(f"the {args.gpus}-rank run printed {len(lines)} JSON lines, expected one")
+    for ln in (lines if r.returncode == 0 else r.stdout.splitlines()):
+        print(ln, flush=True)
+    raise SystemExit(r.returncode)
+
+
+def rehearse_comm(args, world, rank):
+    """--rehearse-comm: everything of the N > 1 path that needs no device — rendezvous, the banded gather of strips whose content is a
+    function of (global row, column), the job report — checked on rank 0 and printed as a line of the usual shape (value 0: nothing was traced)."""
+    import torch
+    import torch.distributed as dist
+    import rtx_pkg
+    rtx = rtx_pkg.load()
+    dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
+    W, H = args.width or 64, args.height or 43
+    rows = rtx.distributed.band_rows(H, world, rank)
+    per = rtx.distributed.band_rows_padded(H, world)
+    strip = torch.zeros(per, W, 4)
+    for i, y in enumerate(rows):
+        strip[i] = (y * W + torch.arange(W, dtype=torch.float32))[:, None] * torch.tensor([1.0, 2.0, 3.0, 0.0]) + torch.tensor([0.0, 0.0, 0.0, 1.0])
+    dist.barrier()
+    t0 = time.perf_counter()
+    image = rtx.distributed.gather_image_banded(strip, H, dist)
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    job = rtx.distributed.job_report(dist, "cpu", "gloo", 0.0, dt, 0.0, gather_ms, strip.numel() * 4)
+    if job["world_seen"] != world:
+        raise SystemExit(f"the process group has {job['world_seen']} ranks, WORLD_SIZE says {world}")
+    if rank == 0:
+        want = (torch.arange(H * W, dtype=torch.float32).reshape(H, W))
+        if not (torch.equal(image[..., 0], want) and torch.equal(image[..., 2], want * 3.0) and bool((image[..., 3] == 1).all())):
+            raise SystemExit("rehearsal: the gathered bands are not in their places")
+        print(json.dumps({"metric": "Mrays/s", "value": 0.0, "unit": "Mrays/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": 0.0,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": f"communication rehearsal without a device: {W}x{H} image in interleaved 8-row bands over {world} ranks, no rendering"},
+                          "per_rank": job["per_rank"], "comm": job["comm"], "roofline": None, "cpu_baseline": None}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def build_workload(rtx, args):
@@ -137,9 +198,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)                        # never returns: one child process runs the N ranks
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match the {world} rank(s) this process was launched as (WORLD_SIZE)")
+    if args.rehearse_comm:
+        return rehearse_comm(args, world, rank)
     import numpy as np
     import torch
     import rtx_pkg

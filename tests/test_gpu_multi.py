@@ -125,6 +125,23 @@ def test_two_gloo_ranks_render_their_bands_on_the_gpu():
     assert out.returncode == 0 and "GLOO_GPU_BANDS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_bench_started_plainly_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` started plainly: bench.py launches the two ranks itself (child torch.distributed.run) and relays one
+    line.  Rehearsed on the box's one GPU: both ranks on device 0 (RTX_BENCH_DEVICE), gloo for the gather; real kernels, real bands."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RTX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "200",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["comm"]["world_seen"] == 2 and line["comm"]["backend"] == "gloo"
+    assert line["value"] > 0 and all(r > 0 for r in line["per_rank"]["rays"]) and len(line["per_rank"]["rays"]) == 2
+
+
 def test_bench_line_through_rccl_with_a_process_group_of_one():
     """bench.py's N > 1 code path on the one GPU of the box: RTX_BENCH_FORCE_DIST=1 makes a single rank initialise RCCL through
     torch.distributed (backend "nccl", device_id), run the barriers, the frame-end gather and the job report's all_gather for real.

@@ -217,6 +217,25 @@ def test_two_rank_gloo_strips_assemble_to_the_full_image():
     assert "GLOO_STRIPS_OK" in r.stdout and "GLOO_BANDS_OK" in r.stdout and "GLOO_JOB_REPORT_OK" in r.stdout      # (the last: bench.py's N > 1 numbers)
 
 
+def test_bench_started_plainly_with_two_ranks_launches_them_itself():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the way the driver starts --gpus 1): bench.py starts the two
+    ranks with torch.distributed.run as a child process and relays ONE line.  Without a device only the communication half can run
+    (--rehearse-comm: rendezvous, the banded gather, the job report; the rendering half is tests/test_gpu_multi.py's)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rehearse-comm", "--width", "40", "--height", "27"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["comm"]["world_seen"] == 2 and line["comm"]["backend"] == "gloo" and len(line["per_rank"]["rays"]) == 2
+    # a rank count that contradicts --gpus is refused instead of silently accepted
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rehearse-comm"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match" in r.stderr
+
+
 def test_cpp_host_marshals_the_same_bytes_as_the_python_host(rtx, tmp_path):
     """Compiled host (host_cpp/: C++ RayTracingManager / RayTracedMesh / ... + .unity loader) == host.py, byte for byte,
     on scenes written as Unity YAML (spheres + triangle meshes with rotated, non-uniformly scaled transforms)."""
