@@ -163,7 +163,7 @@ typedef struct rt_stats {
     int32_t  bvhRepads;                 /* times the box padding was widened on the device (a ray origin moved beyond the magnitude the
                                            boxes were padded for: refit of the existing tree, no rebuild, no re-upload)   */
     int32_t  lastSampleLanes;           /* Philox mode: lanes of a wave that shared a pixel's samples in the last launch (16, 4 or 1) */
-    int32_t  _reserved;
+    int32_t  queuedLaunches;            /* launches the rt_submit_frame queue has made since rt_reset_accum                */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -210,6 +210,9 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "bvh_bins", "bvh_cost_exp", "bvh_reinsert"   BVH builder: SAH bins per axis (32); exponent, in percent, of the triangle
  *                     count in the SAH's subtree-cost model (100); passes of insertion-based optimisation of the binary tree (0:
  *                     measured -3 % node visits per ray but no fewer wave-level steps)
+ *   "bvh_collapse", "bvh_node_cost"   host builder: how the binary SAH tree becomes 4-wide nodes — 0 = greedy, open the child of largest
+ *                     area (default); 1 = cost-driven dynamic programme that also forms the leaves; 2 = the same over the split search's
+ *                     leaves; with a node step costing bvh_node_cost percent of a triangle test (130)
  *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (30, with the groups' item tables = five workgroups per CU); a BVH whose worst
  *                     case is deeper spills the rest to global memory
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
@@ -243,6 +246,8 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     this percentage of its value right after the last build (default 200; 0 = never)
  *   "compact_nodes"   k_trace / k_stream: 1 = traverse the f16 form of the BVH nodes (5 loads per node visit, default), 0 = the
  *                     f32 form (7 loads)
+ *   "queue_depth", "queue_linger_us"   rt_submit_frame: most frames the queue's worker puts into one launch (1..256, default 64); how long
+ *                     it waits for more frames after the first one of an idle queue arrived (default 200 us: a burst becomes one launch)
  *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);
 
@@ -266,6 +271,16 @@ int rt_render_counting(rt_ctx* ctx, int first_frame, int n_frames);
 /* Same frame computed by the reference's own flat loop (all spheres, all chunks, all triangles of
  * passing chunks) on the GPU — a validation/baseline path, not the fast path.                          */
 int rt_render_frame_flat(rt_ctx* ctx, int frame_index);
+
+/* Queued submission for a host that renders frame by frame, as the reference does (one trace blit + one accumulate blit per
+ * OnRenderImage, RayTracingManager.cs:74-91).  rt_submit_frame returns at once; a worker thread of the library traces what has queued
+ * up while the previous launch ran — consecutive frame indices share ONE launch (frame-interleaved work items, one launch tail: the
+ * batched rate instead of the single-frame rate) — and accumulates in submission order, so the image equals rt_render's over the same
+ * frames bit for bit.  rt_wait returns when everything submitted is in resultTexture; every other call on the context waits first, so
+ * reading, changing the camera or uploading between submissions is always safe.  An error of a queued launch is reported (once) by
+ * the next call that waits.  Option "queue_depth": most frames per launch (default 64).                                        */
+int rt_submit_frame(rt_ctx* ctx, int frame_index);
+int rt_wait(rt_ctx* ctx);
 
 /* Zero the accumulation target and the frame counter (RayTracingManager.Start, :43-46).                */
 int rt_reset_accum(rt_ctx* ctx);
@@ -302,7 +317,8 @@ int rt_read_bvh(rt_ctx* ctx, void* nodes_f32, void* nodes_f16, size_t n_nodes);
  * tests exercise this path).  Scene and uniforms are replicated (rt_multi_set_params / rt_multi_upload_* replace the same
  * RayTracingManager calls as their single-device forms); context i renders the 8-row bands b with b % N == i
  * (rt_set_bands(i, N)); rt_multi_render runs the N contexts concurrently for all n_frames and ends with the path's only
- * exchange: one gather of the accumulated strips to the first device (N - 1 peer copies over xGMI + a row scatter).  The
+ * exchange: one gather of the accumulated strips to the first device (N - 1 peer copies over xGMI, each issued on its source
+ * context's stream so that the links run concurrently, joined by events on the first device's stream + a row scatter).  The
  * assembled image is bit-identical to a single-context render (tested).  rt_multi_context gives the per-device context for
  * options, statistics and per-strip read-back.                                                                         */
 typedef struct rt_multi rt_multi;
@@ -315,13 +331,22 @@ int rt_multi_set_params      (rt_multi* m, const rt_params* params);
 int rt_multi_upload_spheres  (rt_multi* m, const rt_sphere*   spheres,  int n);
 int rt_multi_upload_triangles(rt_multi* m, const rt_triangle* tris,     int n);
 int rt_multi_upload_meshinfo (rt_multi* m, const rt_meshinfo* meshinfo, int n);
+/* The on-device geometry pipeline behind the handle (rt_upload_local_meshes / rt_set_mesh_transforms for every context): the local
+ * meshes go to every device once, a frame sends the poses (40 B per mesh, RayTracedMesh.cs:36-84: the reference moves meshes every
+ * frame) and every device transforms, builds and refits its own copy — no geometry crosses xGMI per frame.                       */
+int rt_multi_upload_local_meshes(rt_multi* m, const rt_triangle* local_tris, int n_tris, const rt_local_chunk* chunks, int n_chunks, int n_meshes);
+int rt_multi_set_mesh_transforms(rt_multi* m, const rt_mesh_transform* transforms, int n_meshes);
 int rt_multi_set_option      (rt_multi* m, const char* name, int value);
 int rt_multi_reset_accum     (rt_multi* m);
 int rt_multi_render          (rt_multi* m, int first_frame, int n_frames);
 /* the assembled resultTexture: height*width*4 floats, row 0 = bottom */
 int rt_multi_read_accum      (rt_multi* m, float* rgba, size_t n_floats);
-/* rays and work counters summed over the contexts, kernel times = the slowest context's; gather_ms (may be NULL) = HIP-event
- * time of the last gather on the first device                                                                           */
+/* the assembled image through the display step (rt_read_display's twin: linear -> sRGB8 on the first device; height*width pixels) */
+int rt_multi_read_display    (rt_multi* m, uint32_t* rgba8, size_t n_pixels);
+/* restore a saved accumulation state (rt_write_accum's twin): the whole image in, every context takes the rows of its bands */
+int rt_multi_write_accum     (rt_multi* m, const float* rgba, size_t n_floats, int frames_rendered);
+/* rays and work counters summed over the contexts, kernel times = the slowest context's; gather_ms (may be NULL) = wall
+ * time of the last gather (copies + scatter)                                                                            */
 int rt_multi_get_stats       (rt_multi* m, rt_stats* out, double* gather_ms);
 /* How the handle is set up and what a scene change cost: the uploads go to the first context only, which builds the scene once;
  * the other contexts receive the built scene device to device (over xGMI between GPUs) — bvhBuilds counts the builds of ALL
@@ -330,7 +355,7 @@ typedef struct rt_multi_info {
     int32_t numContexts;
     int32_t bvhBuilds;                  /* BVH builds summed over the contexts since rt_multi_create                        */
     double  lastSetupMs;                /* host wall time of the last scene change: build on the first context + fan-out   */
-    double  lastGatherMs;               /* HIP-event time of the last gather                                               */
+    double  lastGatherMs;               /* host wall time of the last gather: first copy submitted -> image assembled    */
     int32_t device[16];                 /* HIP ordinal of context i (the first 16)                                         */
     int32_t peerAccess[16];             /* 1: the first context's device and context i's read each other's memory directly */
                                         /* (copies go GPU to GPU over xGMI), 0: the runtime stages them; [0] = 1            */

@@ -42,7 +42,7 @@ STATS = np.dtype([
     ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"), ("lastGeometryMs", "<f8"), ("lastDisplayMs", "<f8"), ("lastFramesPerLaunch", "<i4"), ("autoKernel", "<i4"),
     ("lastKernel", "<i4"), ("lastFramesInterleaved", "<i4"),
     ("lastBvhBuildMs", "<f8"), ("refitAreaRatio", "<f4"), ("bvhInternalArea", "<f4"), ("bvhBuiltOnDevice", "<i4"), ("bvhBuilds", "<i4"),
-    ("bvhRebuilds", "<i4"), ("bvhRepads", "<i4"), ("lastSampleLanes", "<i4"), ("_reserved", "<i4"),
+    ("bvhRebuilds", "<i4"), ("bvhRepads", "<i4"), ("lastSampleLanes", "<i4"), ("queuedLaunches", "<i4"),
 ])
 MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])
 MULTI_INFO = np.dtype([("numContexts", "<i4"), ("bvhBuilds", "<i4"), ("lastSetupMs", "<f8"), ("lastGatherMs", "<f8"),
@@ -60,10 +60,11 @@ SYMBOLS = [
     "rt_upload_triangles", "rt_upload_meshinfo", "rt_set_rows", "rt_render_frame", "rt_render",
     "rt_render_counting", "rt_render_frame_flat", "rt_reset_accum", "rt_read_accum", "rt_read_last_frame",
     "rt_copy_accum_to_device", "rt_get_stats", "rt_abi_version", "rt_sizeof", "rt_set_option", "rt_set_bands", "rt_upload_local_meshes", "rt_set_mesh_transforms", "rt_read_world_geometry", "rt_read_display",
-    "rt_read_bvh", "rt_write_accum",
+    "rt_read_bvh", "rt_write_accum", "rt_submit_frame", "rt_wait",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_count", "rt_multi_context", "rt_multi_set_params",
     "rt_multi_upload_spheres", "rt_multi_upload_triangles", "rt_multi_upload_meshinfo", "rt_multi_set_option", "rt_multi_reset_accum",
     "rt_multi_render", "rt_multi_read_accum", "rt_multi_get_stats", "rt_multi_get_info",
+    "rt_multi_upload_local_meshes", "rt_multi_set_mesh_transforms", "rt_multi_read_display", "rt_multi_write_accum",
 ]
 
 _lib = None
@@ -103,6 +104,8 @@ def load_library() -> ctypes.CDLL:
     lib.rt_render.argtypes = [c_void_p, c_int, c_int]
     lib.rt_render_counting.argtypes = [c_void_p, c_int, c_int]
     lib.rt_reset_accum.argtypes = [c_void_p]
+    lib.rt_submit_frame.argtypes = [c_void_p, c_int]
+    lib.rt_wait.argtypes = [c_void_p]
     lib.rt_read_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t]
     lib.rt_read_last_frame.argtypes = [c_void_p, POINTER(c_float), c_size_t]
     lib.rt_copy_accum_to_device.argtypes = [c_void_p, c_void_p, c_size_t]
@@ -130,6 +133,10 @@ def load_library() -> ctypes.CDLL:
     lib.rt_multi_read_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t]
     lib.rt_multi_get_stats.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.rt_multi_get_info.argtypes = [c_void_p, c_void_p]
+    lib.rt_multi_upload_local_meshes.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int]
+    lib.rt_multi_set_mesh_transforms.argtypes = [c_void_p, c_void_p, c_int]
+    lib.rt_multi_read_display.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.rt_multi_write_accum.argtypes = [c_void_p, POINTER(c_float), c_size_t, c_int]
     for n in SYMBOLS:
         f = getattr(lib, n)
         if f.restype is None or n in ("rt_create", "rt_last_error", "rt_destroy", "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error",
@@ -260,6 +267,13 @@ class Tracer:
         self._check(self._lib.rt_read_accum(self._ctx, out.ctypes.data_as(POINTER(c_float)), out.size), "rt_read_accum")
         return out
 
+    def submit_frame(self, frame_index: int):
+        """Queue one frame (returns at once); wait() or any other call makes sure it is in resultTexture."""
+        self._check(self._lib.rt_submit_frame(self._ctx, int(frame_index)), "rt_submit_frame")
+
+    def wait(self):
+        self._check(self._lib.rt_wait(self._ctx), "rt_wait")
+
     def write_accum(self, rgba, frames_rendered: int):
         """Restore a saved resultTexture (as read_accum returned it) and the frame counter."""
         a = np.ascontiguousarray(rgba, np.float32)
@@ -341,6 +355,27 @@ class MultiTracer:
             if arr is not None:
                 a, ptr, n = _as_buffer(arr, dt)
                 self._check(getattr(self._lib, fn)(self._m, ptr, n), fn)
+
+    def upload_local_meshes(self, local_tris, chunks, n_meshes: int):
+        t, tp, nt = _as_buffer(local_tris, TRIANGLE)
+        ch, cp, nc = _as_buffer(chunks, LOCAL_CHUNK)
+        self._check(self._lib.rt_multi_upload_local_meshes(self._m, tp, nt, cp, nc, int(n_meshes)), "rt_multi_upload_local_meshes")
+
+    def set_mesh_transforms(self, transforms):
+        x, xp, n = _as_buffer(transforms, MESH_TRANSFORM)
+        self._check(self._lib.rt_multi_set_mesh_transforms(self._m, xp, n), "rt_multi_set_mesh_transforms")
+
+    def read_display(self) -> np.ndarray:
+        """the assembled resultTexture as sRGB RGBA8, shape (H, W, 4) uint8, row 0 = bottom"""
+        H, W = self._shape
+        out = np.empty((H, W), np.uint32)
+        self._check(self._lib.rt_multi_read_display(self._m, out.ctypes.data_as(c_void_p), out.size), "rt_multi_read_display")
+        return out.view(np.uint8).reshape(H, W, 4)
+
+    def write_accum(self, rgba, frames_rendered: int):
+        """Restore a saved resultTexture (the whole image, as read_accum returned it) and the frame counter on every context."""
+        a = np.ascontiguousarray(rgba, np.float32)
+        self._check(self._lib.rt_multi_write_accum(self._m, a.ctypes.data_as(POINTER(c_float)), a.size, int(frames_rendered)), "rt_multi_write_accum")
 
     def set_option(self, name: str, value: int):
         self._check(self._lib.rt_multi_set_option(self._m, name.encode(), int(value)), f"rt_multi_set_option({name})")

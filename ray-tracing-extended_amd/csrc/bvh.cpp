@@ -286,7 +286,8 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
     if (n_tris == 0) return;
 
     Builder B; B.pos = tri_pos; B.stride = stride_floats; B.n = n_tris;
-    B.max_leaf = std::min(std::max(max_leaf, 1), kMaxLeaf);
+    const int B_max_leaf = std::min(std::max(max_leaf, 1), kMaxLeaf);
+    B.max_leaf = tuning.collapse_dp == 1 ? 1 : B_max_leaf;          // (cost-driven collapse 1: the dynamic programme forms the leaves; 2: the split search does, as for the greedy collapse)
     B.g_bins = std::min(std::max(tuning.bins, 2), 128);
     B.g_cost_exp = (float)std::min(std::max(tuning.cost_exp_percent, 10), 300) / 100.0f;
     B.tbox.resize(n_tris); B.cent.resize(3 * (size_t)n_tris); B.idx.resize(n_tris);
@@ -301,7 +302,7 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
         }
         B.idx[t] = t;
     }
-    B.bn.reserve(2 * (size_t)n_tris / 2 + 16);
+    B.bn.reserve(2 * (size_t)n_tris + 16);
     int root = B.build_range(0, n_tris, 0);
     if (g_reinsert_passes > 0 && B.bn.size() > 7) {
         Reinserter R(B.bn, root);
@@ -323,6 +324,82 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
     out.magnitude = G;
     out.depth = B.depth;
 
+    // ---- which binary nodes become children of which 4-wide node: cost-driven collapse (after Ylitie, Karras, Laine, "Efficient
+    // incoherent ray traversal on GPUs through compressed wide BVHs", HPG 2017, section 4.1; width 4, leaves of <= max_leaf triangles).
+    // A node step tests four slots whether they are used or not, so an empty slot is wasted work: the greedy "open the largest child"
+    // collapse left 3.1 of 4 slots used on the 100k-triangle workload.  Here the binary tree goes down to single triangles and a
+    // dynamic programme picks, per binary node n and i = 1..4,
+    //     C(n, i) = the cheapest way to represent n's subtree by at most i children of a wide node
+    //     C(n, 1) = min( leaf: area(n) * triangles * Ct  [triangles <= max_leaf],   wide node: area(n) * Cn + D(n, 4) )
+    //     C(n, i) = min( C(n, i - 1),  D(n, i) ),    D(n, j) = min over k of C(left, k) + C(right, j - k)
+    // (expected cost of a random ray: every visited wide node costs a node step Cn, every visited leaf its triangle tests Ct, both
+    // in proportion to their box area).  Leaves may split into smaller ones where a free slot makes that cheaper.
+    const bool dp = tuning.collapse_dp != 0;
+    const float Cn = (float)std::min(std::max(tuning.node_cost_percent, 1), 10000) / 100.0f, Ct = 1.0f;
+    std::vector<double> C;              // [node][4]
+    std::vector<uint8_t> pick;          // [node][4]: [0] 1 = leaf / 0 = wide node; [i >= 1] for at most i + 1 children: 0 = same as i, else k = children given to the left
+    std::vector<uint8_t> pick4;         // [node]: k of D(n, 4) (children of the wide node rooted at n that come from the left subtree)
+    std::vector<uint32_t> ntri;
+    if (dp) {
+        const size_t nb = B.bn.size();
+        C.assign(4 * nb, 0.0); pick.assign(4 * nb, 0); pick4.assign(nb, 0); ntri.assign(nb, 0);
+        // children were created after their parent unless the tree was rewired: explicit post-order
+        std::vector<int> postorder; postorder.reserve(nb);
+        { std::vector<int> st; st.push_back(root);
+          while (!st.empty()) { int n = st.back(); st.pop_back(); postorder.push_back(n);
+                                if (B.bn[n].count == 0) { st.push_back(B.bn[n].left); st.push_back(B.bn[n].right); } } }
+        const double INF = std::numeric_limits<double>::infinity();
+        for (size_t q = postorder.size(); q-- > 0;) {
+            const int n = postorder[q];
+            const BNode& N = B.bn[n];
+            // (a box with a NaN or an infinity in it — degenerate input — must not poison the comparisons: its area counts as 0 or as huge)
+            const float Af = N.box.half_area();
+            const double A = Af == Af ? std::min((double)Af, 1.0e30) : 0.0;
+            double* c = &C[4 * (size_t)n]; uint8_t* pk = &pick[4 * (size_t)n];
+            if (N.count > 0) {
+                ntri[n] = N.count;
+                for (int i = 0; i < 4; ++i) c[i] = A * (double)N.count * Ct;
+                pk[0] = 1;
+                continue;
+            }
+            const int l = N.left, r = N.right;
+            ntri[n] = ntri[l] + ntri[r];
+            const double* cl = &C[4 * (size_t)l]; const double* cr = &C[4 * (size_t)r];
+            double D[5]; uint8_t Dk[5];
+            for (int j = 2; j <= 4; ++j) {
+                D[j] = INF; Dk[j] = 1;
+                for (int k = 1; k < j; ++k) { const double v = cl[k - 1] + cr[j - k - 1]; if (v < D[j]) { D[j] = v; Dk[j] = (uint8_t)k; } }
+            }
+            const double c_wide = A * Cn + D[4];
+            const bool may_leaf = ntri[n] <= (uint32_t)B_max_leaf;
+            const double c_leaf = may_leaf ? A * (double)ntri[n] * Ct : INF;
+            pick4[n] = Dk[4];
+            if (may_leaf && c_leaf <= c_wide) { c[0] = c_leaf; pk[0] = 1; } else { c[0] = c_wide; pk[0] = 0; }
+            for (int i = 2; i <= 4; ++i) {
+                if (D[i] < c[i - 2]) { c[i - 1] = D[i]; pk[i - 1] = Dk[i]; } else { c[i - 1] = c[i - 2]; pk[i - 1] = 0; }
+            }
+        }
+    }
+    // the children (binary nodes) of the wide node rooted at binary node n
+    struct Kid { int bnode; bool leaf; };
+    auto kids_of = [&](int n, Kid* out_k) -> int {
+        int nk = 0;
+        struct Item { int node, i; };           // represent `node` by at most i children
+        Item st[16]; int sp = 0;
+        const int k4 = pick4[n];
+        st[sp++] = { B.bn[n].right, 4 - k4 }; st[sp++] = { B.bn[n].left, k4 };
+        while (sp > 0) {
+            Item it = st[--sp];
+            while (it.i > 1 && pick[4 * (size_t)it.node + it.i - 1] == 0) --it.i;
+            if (it.i == 1) { out_k[nk++] = { it.node, pick[4 * (size_t)it.node] != 0 }; continue; }
+            const int k = pick[4 * (size_t)it.node + it.i - 1];
+            st[sp++] = { B.bn[it.node].right, it.i - k }; st[sp++] = { B.bn[it.node].left, k };
+        }
+        return nk;
+    };
+    // first triangle (BVH order) of a binary subtree: its leftmost leaf's
+    auto first_tri = [&](int n) -> uint32_t { while (B.bn[n].count == 0) n = B.bn[n].left; return B.bn[n].first; };
+
     // ---- collapse to 4-wide, breadth-first ----
     struct Pending { int bnode; uint32_t slot; int level; };
     std::vector<Node4>& N = out.nodes;
@@ -343,8 +420,12 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
     while (!q.empty()) {
         Pending pd = q.front(); q.pop();
         if ((int)out.levelStart.size() <= pd.level) out.levelStart.push_back(pd.slot);
-        int kids[4]; int nk = 0;
+        int kids[4]; bool kid_leaf[4]; int nk = 0;
         const BNode& r = B.bn[pd.bnode];
+        if (dp) {
+            if (r.count > 0 || pick[4 * (size_t)pd.bnode] != 0) { kids[nk] = pd.bnode; kid_leaf[nk++] = true; }     // the whole mesh fits one leaf
+            else { Kid kk[4]; nk = kids_of(pd.bnode, kk); for (int k = 0; k < nk; ++k) { kids[k] = kk[k].bnode; kid_leaf[k] = kk[k].leaf; } }
+        } else {
         if (r.count > 0) { kids[nk++] = pd.bnode; }         // the whole mesh fits one leaf
         else { kids[nk++] = r.left; kids[nk++] = r.right; }
         while (nk < 4) {                                    // open the internal child with the largest area
@@ -359,12 +440,14 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
             kids[pick] = B.bn[c].left;
             kids[nk++] = B.bn[c].right;
         }
+        for (int k = 0; k < nk; ++k) kid_leaf[k] = B.bn[kids[k]].count > 0;
+        }
         for (int k = 0; k < nk; ++k) {
             const BNode& c = B.bn[kids[k]];
             float mn[3], mx[3];
             pad_box(c.box, G, mn, mx);
             uint32_t ref;
-            if (c.count > 0) ref = make_leaf(c.first, c.count);
+            if (kid_leaf[k]) ref = dp ? make_leaf(first_tri(kids[k]), ntri[kids[k]]) : make_leaf(c.first, c.count);
             else { ref = new_node(); q.push({ kids[k], ref, pd.level + 1 }); }
             Node4& me = N[pd.slot];                          // (re-fetch: new_node may reallocate)
             me.minx[k] = mn[0]; me.miny[k] = mn[1]; me.minz[k] = mn[2];

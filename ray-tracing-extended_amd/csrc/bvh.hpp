@@ -89,7 +89,12 @@ struct Bvh {
 // Builder tuning, per call (two contexts on two host threads build independently): SAH bins per axis (2..128), the exponent,
 // in percent, of the triangle count in the SAH's subtree-cost model area * count^e, passes of insertion-based optimisation of
 // the binary tree, triangles per leaf (1..kMaxLeaf).  The hierarchy changes, the closest hit it returns does not.
-struct Tuning { int bins = 32; int cost_exp_percent = 100; int reinsert_passes = 0; int max_leaf = 2; };
+struct Tuning { int bins = 32; int cost_exp_percent = 100; int reinsert_passes = 0; int max_leaf = 2;
+                // collapse of the binary tree to 4-wide nodes: 0 = greedy (open the child of largest area; default — measured best on the
+                // headline scene, profiles/bvh_collapse_r04.txt), 1 = cost-driven (dynamic programme over "at most i children" per binary
+                // node, leaves formed by it), 2 = cost-driven over the split search's own leaves; node_cost_percent = cost of a node step in percent of a
+                // triangle test's (measured on MI355X: 345 against 265 SIMD cycles per wave-level execution)
+                int collapse_dp = 0; int node_cost_percent = 130; };
 
 // tri_pos: 9 floats per triangle (posA, posB, posC) every stride_floats.  origin_magnitude = largest |coordinate| a ray origin
 // outside the triangles can have (the camera, sphere surfaces): it widens the absolute part of the box padding.

@@ -6,7 +6,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -94,6 +98,7 @@ struct rt_ctx {
     size_t n_nodes = 0;             // BVH4 nodes on the device
     rtgb::Workspace bvh_ws;         // device builder's scratch
     float area_at_build = 0.f;      // sum of internal child-box areas right after the last build (refit quality monitor)
+    float area_after_refit = 0.f;   // ... after the last refit: written by an asynchronous copy, so it lives in the context, not on a stack
     int opt_device_bvh = -1;        // 1: build the BVH on the device (Morton order + PLOC + collapse), 0: host binned-SAH builder,
                                     // -1: device for the on-device geometry pipeline (meshes that move), host for world-space uploads
                                     // (a static scene is built once and traced for many frames: the SAH tree is traced 4-16 % faster,
@@ -130,12 +135,25 @@ struct rt_ctx {
     int opt_bvh_reinsert = 0;       // BVH builder: insertion-based optimisation passes
     int opt_bvh_bins = 32, opt_bvh_cost_exp = 100;   // BVH builder: SAH bins per axis; exponent (percent) of the count in the SAH cost model
     int opt_max_leaf = 2;           // BVH: triangles per leaf (measured best on the 100k-triangle workload: 2)
+    int opt_bvh_collapse = 0;       // host builder: 0 = greedy collapse of the binary tree to 4-wide nodes (open the largest child), 1 / 2 = cost-driven (bvh.cpp;
+                                    // measured -4.4 % / -1.5 % on the headline scene, -1.4 % / +1.5 % on the million-triangle one: profiles/bvh_collapse_r04.txt)
+    int opt_bvh_node_cost = 130;    // ... with a node step costing this many percent of a triangle test
     int opt_stream_stack = 30;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory.  30 entries + the groups' item
                                     // tables = 31,744 B per workgroup: five workgroups per CU (32,768 B already makes it four: measured -11 %)
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     DevBuf<uint32_t> d_gstack;
     DevBuf<float> d_park;              // k_stream, Philox mode: parked sub-stream sums
     rt_stats stats{};
+
+    // ---- queued submission (rt_submit_frame / rt_wait): frames handed in one by one — the reference's OnRenderImage pattern,
+    // RayTracingManager.cs:74-91 — are traced by a worker thread in launches of whatever has queued up while the previous launch ran
+    std::thread q_thread; bool q_started = false;
+    std::mutex q_mu; std::condition_variable q_cv, q_idle;
+    std::deque<int> q_frames; bool q_busy = false, q_stop = false;
+    int q_rc = 0; std::string q_err;
+    int opt_queue_depth = 64;       // most frames the worker puts into one launch
+    int opt_queue_linger_us = 200;  // after the first frame of an idle queue arrives the worker waits this long for more (a host that submits a burst
+                                    // of frames gets one launch for it; a host that submits one frame per display refresh pays 0.2 ms)
 };
 
 namespace {
@@ -217,6 +235,7 @@ rtbvh::Tuning bvh_tuning(const rt_ctx* c)
 {
     rtbvh::Tuning t;
     t.bins = c->opt_bvh_bins; t.cost_exp_percent = c->opt_bvh_cost_exp; t.reinsert_passes = c->opt_bvh_reinsert; t.max_leaf = c->opt_max_leaf;
+    t.collapse_dp = c->opt_bvh_collapse; t.node_cost_percent = c->opt_bvh_node_cost;
     return t;
 }
 
@@ -446,14 +465,14 @@ int run_geometry_kernels(rt_ctx* c, bool have_bvh)
     // summed in the same pass (one more small kernel and a 4-byte copy before the one synchronisation, inside lastGeometryMs); once it
     // has grown past the threshold the tree is rebuilt on the device (cheaper than one frame) instead of refitted.
     const bool check_area = have_bvh && nt && c->opt_device_bvh != 0 && c->opt_rebuild_percent > 0 && c->area_at_build > 0.f;
-    float area = 0.f;
-    if (check_area) RT_HIP(c, rtgb::internal_area_async(c->stream, reinterpret_cast<const rtbvh::Node4*>(c->d_nodes.p), (uint32_t)c->n_nodes, c->bvh_ws, &area));
+    if (check_area) RT_HIP(c, rtgb::internal_area_async(c->stream, reinterpret_cast<const rtbvh::Node4*>(c->d_nodes.p), (uint32_t)c->n_nodes, c->bvh_ws, &c->area_after_refit));
     RT_HIP(c, hipEventRecord(c->evg1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
     c->stats.lastGeometryMs = ms;
     if (check_area) {
+        const float area = c->area_after_refit;
         c->stats.refitAreaRatio = area / c->area_at_build;
         if (area > c->area_at_build * (float)c->opt_rebuild_percent / 100.0f) {
             int r = device_build(c, nt, local_scene_magnitude(c)); if (r) return r;
@@ -640,8 +659,8 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (philox && var == Variant::Flat) return fail(c, -2, "the flat validation kernel implements the PCG stream only");
     if (philox) kernel = 1;
     if (philox && (c->target_w > 65535 || c->target_rows > 65535)) return fail(c, -7, "the Philox mode addresses at most 65535 x 65535 pixels per context");
-    if (philox && (c->params.numRaysPerPixel > 65000 || c->params.maxBounceCount > 65000))
-        return fail(c, -7, "the Philox mode takes at most 65000 rays per pixel per frame and 65000 bounces (16-bit sample and bounce counters)");
+    if (philox && (c->params.numRaysPerPixel > 65000 || c->params.maxBounceCount > 32000))
+        return fail(c, -7, "the Philox mode takes at most 65000 rays per pixel per frame and 32000 bounces (sample and bounce share one signed 32-bit register)");
     const bool stream = kernel == 1 && var != Variant::Flat && c->params.numRaysPerPixel >= 1        // PCG or Philox instantiation
                         && c->target_w <= 65535 && c->target_rows <= 65535;                          // (16-bit pixel coordinates in k_stream's item tables)
     F.stack_cap = std::max(1, c->bvh.maxStack) + (stream ? 3 : 0);    // the branch-free push writes up to 3 slots past the top
@@ -826,7 +845,12 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
     if (c->auto_choice >= 0 && !c->scene_dirty && order_ready())
         return launch_frames_k(c, first_frame, n_frames, var, decided(n_frames));
 
-    if (n_frames == 0) return launch_frames_k(c, first_frame, 0, var, c->auto_choice >= 0 ? c->auto_choice : 0);   // scene / geometry update only
+    if (n_frames == 0) {            // scene / geometry update only (rt_multi's build on its first context)
+        const bool was_dirty = c->scene_dirty;
+        const int r = launch_frames_k(c, first_frame, 0, var, c->auto_choice >= 0 ? c->auto_choice : 0);
+        if (was_dirty) { c->auto_choice = -1; c->auto_ms[0] = c->auto_ms[1] = -1.0; }     // a new scene is measured again, as on the contexts that receive it
+        return r;
+    }
     rt_stats sum{}; bool any = false;
     auto add = [&]() {
         const rt_stats& s = c->stats;
@@ -882,6 +906,43 @@ int read_target(rt_ctx* c, bool accum, float* dst, size_t n_floats, bool to_devi
     return 0;
 }
 
+// ---- queued submission ----------------------------------------------------------------------------------------------------------
+void queue_worker(rt_ctx* c)
+{
+    std::unique_lock<std::mutex> lk(c->q_mu);
+    for (;;) {
+        c->q_cv.wait(lk, [&] { return c->q_stop || !c->q_frames.empty(); });
+        if (c->q_frames.empty()) break;                 // (stop is honoured once the queue has drained)
+        if (c->opt_queue_linger_us > 0 && !c->q_stop)
+            c->q_cv.wait_for(lk, std::chrono::microseconds(c->opt_queue_linger_us), [&] { return c->q_stop || (int)c->q_frames.size() >= c->opt_queue_depth; });
+        // the longest run of consecutive frame indices at the head of the queue: one launch (rt_render(first, n))
+        const int first = c->q_frames.front(); int n = 0;
+        while (!c->q_frames.empty() && c->q_frames.front() == first + n && n < c->opt_queue_depth) { c->q_frames.pop_front(); ++n; }
+        c->q_busy = true;
+        const bool failed = c->q_rc != 0;
+        lk.unlock();
+        const int r = failed ? 0 : launch_frames(c, first, n, Variant::Fast);      // after a failure the rest of the queue is dropped
+        lk.lock();
+        if (r && !c->q_rc) { c->q_rc = r; c->q_err = c->err; }
+        if (!failed && !r) c->stats.queuedLaunches++;
+        c->q_busy = false;
+        c->q_idle.notify_all();
+    }
+}
+
+// Every entry point but rt_submit_frame starts here: the queue is empty and the worker idle before anything else touches the context
+// (a context has one caller thread; the worker is the library's own).  Returns the first error a queued launch met, once.
+int settle(rt_ctx* c)
+{
+    if (!c->q_started) return 0;
+    std::unique_lock<std::mutex> lk(c->q_mu);
+    c->q_idle.wait(lk, [&] { return c->q_frames.empty() && !c->q_busy; });
+    const int r = c->q_rc;
+    if (r) { c->err = "queued frame: " + c->q_err; c->q_rc = 0; }
+    return r;
+}
+#define RT_SETTLE(c) do { const int qr_ = settle(c); if (qr_) return qr_; } while (0)
+
 } // namespace
 
 extern "C" {
@@ -933,6 +994,11 @@ rt_ctx* rt_create(int device)
 void rt_destroy(rt_ctx* c)
 {
     if (!c) return;
+    if (c->q_started) {
+        { std::lock_guard<std::mutex> lk(c->q_mu); c->q_stop = true; }
+        c->q_cv.notify_all();
+        c->q_thread.join();
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
@@ -953,6 +1019,7 @@ void rt_destroy(rt_ctx* c)
 int rt_set_stream(rt_ctx* c, void* hip_stream)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return 0;
 }
@@ -960,6 +1027,7 @@ int rt_set_stream(rt_ctx* c, void* hip_stream)
 int rt_set_params(rt_ctx* c, const rt_params* p)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (!p) return fail(c, -2, "null params");
     if (p->width < 0 || p->height < 0 || (int64_t)p->width * p->height > (int64_t)1 << 31) return fail(c, -2, "bad target size %dx%d", p->width, p->height);
     if (p->numRaysPerPixel < 0) return fail(c, -2, "numRaysPerPixel < 0");
@@ -975,6 +1043,7 @@ int rt_set_params(rt_ctx* c, const rt_params* p)
 int rt_upload_spheres(rt_ctx* c, const rt_sphere* s, int n)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (n < 0 || (n > 0 && !s)) return fail(c, -2, "bad sphere upload (n=%d)", n);
     c->h_spheres.assign(s, s + n); c->scene_dirty = true;
     return 0;
@@ -982,6 +1051,7 @@ int rt_upload_spheres(rt_ctx* c, const rt_sphere* s, int n)
 int rt_upload_triangles(rt_ctx* c, const rt_triangle* t, int n)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (n < 0 || (n > 0 && !t)) return fail(c, -2, "bad triangle upload (n=%d)", n);
     c->h_tris.assign(t, t + n); c->scene_dirty = true; c->geom_local = false;
     return 0;
@@ -989,6 +1059,7 @@ int rt_upload_triangles(rt_ctx* c, const rt_triangle* t, int n)
 int rt_upload_meshinfo(rt_ctx* c, const rt_meshinfo* m, int n)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (n < 0 || (n > 0 && !m)) return fail(c, -2, "bad meshinfo upload (n=%d)", n);
     c->h_mesh.assign(m, m + n); c->scene_dirty = true; c->geom_local = false;
     return 0;
@@ -997,6 +1068,7 @@ int rt_upload_meshinfo(rt_ctx* c, const rt_meshinfo* m, int n)
 int rt_upload_local_meshes(rt_ctx* c, const rt_triangle* tris, int n_tris, const rt_local_chunk* chunks, int n_chunks, int n_meshes)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (n_tris < 0 || n_chunks < 0 || n_meshes < 0 || (n_tris > 0 && !tris) || (n_chunks > 0 && !chunks)) return fail(c, -2, "bad local mesh upload");
     if (n_tris > (1 << 28)) return fail(c, -3, "too many triangles (%d)", n_tris);
     std::vector<uint8_t> seen(n_tris, 0);
@@ -1024,6 +1096,7 @@ int rt_upload_local_meshes(rt_ctx* c, const rt_triangle* tris, int n_tris, const
 int rt_set_mesh_transforms(rt_ctx* c, const rt_mesh_transform* xf, int n_meshes)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (n_meshes < 0 || (n_meshes > 0 && !xf)) return fail(c, -2, "bad transform upload");
     if (c->geom_local && n_meshes != c->n_meshes) return fail(c, -2, "%d transforms for %d meshes", n_meshes, c->n_meshes);
     c->h_xf.assign(xf, xf + n_meshes);
@@ -1034,6 +1107,7 @@ int rt_set_mesh_transforms(rt_ctx* c, const rt_mesh_transform* xf, int n_meshes)
 int rt_read_world_geometry(rt_ctx* c, rt_triangle* tris_out, int n_tris, rt_meshinfo* mi_out, int n_chunks)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (!c->geom_local) return fail(c, -2, "no local meshes uploaded");
     if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
     if (n_tris != (int)c->h_local_tris.size() || n_chunks != (int)c->h_lchunks.size()) return fail(c, -2, "size mismatch");
@@ -1056,6 +1130,7 @@ int rt_read_world_geometry(rt_ctx* c, rt_triangle* tris_out, int n_tris, rt_mesh
 int rt_set_option(rt_ctx* c, const char* name, int value)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (!name) return fail(c, -2, "null option name");
     if (!std::strcmp(name, "kernel")) {
         if (value < -1 || value > 1) return fail(c, -2, "kernel must be -1 (auto), 0 (k_trace) or 1 (k_stream)");
@@ -1068,6 +1143,8 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "bvh_reinsert")) { if (value < 0 || value > 16) return fail(c, -2, "bvh_reinsert must be in [0,16]"); if (value != c->opt_bvh_reinsert) c->scene_dirty = true; c->opt_bvh_reinsert = value; }
     else if (!std::strcmp(name, "bvh_cost_exp")) { if (value < 10 || value > 300) return fail(c, -2, "bvh_cost_exp must be in [10,300] (percent)"); if (value != c->opt_bvh_cost_exp) c->scene_dirty = true; c->opt_bvh_cost_exp = value; }
     else if (!std::strcmp(name, "max_leaf")) { if (value < 1 || value > rtbvh::kMaxLeaf) return fail(c, -2, "max_leaf must be in [1,4]"); if (value != c->opt_max_leaf) c->scene_dirty = true; c->opt_max_leaf = value; }
+    else if (!std::strcmp(name, "bvh_collapse")) { if (value < 0 || value > 2) return fail(c, -2, "bvh_collapse must be 0 (greedy), 1 (cost-driven, leaves formed by the collapse) or 2 (cost-driven over the split search's leaves)"); if (value != c->opt_bvh_collapse) c->scene_dirty = true; c->opt_bvh_collapse = value; }
+    else if (!std::strcmp(name, "bvh_node_cost")) { if (value < 1 || value > 10000) return fail(c, -2, "bvh_node_cost must be in [1,10000] (percent of a triangle test)"); if (value != c->opt_bvh_node_cost) c->scene_dirty = true; c->opt_bvh_node_cost = value; }
     else if (!std::strcmp(name, "tile_w_log2")) { if (value < 0 || value > 6) return fail(c, -2, "tile_w_log2 must be in [0,6]"); c->opt_tile_w_log2 = value; }
     else if (!std::strcmp(name, "tile_lpt")) { c->opt_tile_lpt = value ? 1 : 0; c->tile_order_valid = false; }
     else if (!std::strcmp(name, "frame_batch")) { if (value < 0 || value > 1024) return fail(c, -2, "frame_batch must be in [0,1024]"); c->opt_frame_batch = value; }
@@ -1084,6 +1161,8 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "rebuild_percent")) { if (value < 0 || value > 100000) return fail(c, -2, "rebuild_percent must be in [0,100000] (0 = never rebuild)"); c->opt_rebuild_percent = value; }
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
+    else if (!std::strcmp(name, "queue_depth")) { if (value < 1 || value > 256) return fail(c, -2, "queue_depth must be in [1,256]"); c->opt_queue_depth = value; }
+    else if (!std::strcmp(name, "queue_linger_us")) { if (value < 0 || value > 1000000) return fail(c, -2, "queue_linger_us must be in [0,1000000]"); c->opt_queue_linger_us = value; }
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }
     else return fail(c, -2, "unknown option '%s'", name);
     return 0;
@@ -1092,6 +1171,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
 int rt_set_rows(rt_ctx* c, int row0, int nrows)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (row0 < 0 || nrows < 0) return fail(c, -2, "bad row strip (%d,%d)", row0, nrows);
     c->row0 = row0; c->nrows = nrows; c->band_stride = 0;
     return 0;
@@ -1100,32 +1180,53 @@ int rt_set_rows(rt_ctx* c, int row0, int nrows)
 int rt_set_bands(rt_ctx* c, int first_band, int band_stride)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (first_band < 0 || band_stride < 1 || first_band >= band_stride) return fail(c, -2, "bad band pattern (%d,%d)", first_band, band_stride);
     c->band_first = first_band; c->band_stride = band_stride;
     return 0;
 }
 
-int rt_render_frame(rt_ctx* c, int frame_index) { return launch_frames(c, frame_index, 1, Variant::Fast); }
-int rt_render(rt_ctx* c, int first_frame, int n_frames) { return launch_frames(c, first_frame, n_frames, Variant::Fast); }
-int rt_render_counting(rt_ctx* c, int first_frame, int n_frames) { return launch_frames(c, first_frame, n_frames, Variant::Counting); }
-int rt_render_frame_flat(rt_ctx* c, int frame_index) { return launch_frames(c, frame_index, 1, Variant::Flat); }
+int rt_render_frame(rt_ctx* c, int frame_index) { if (!c) return -1; RT_SETTLE(c); return launch_frames(c, frame_index, 1, Variant::Fast); }
+int rt_render(rt_ctx* c, int first_frame, int n_frames) { if (!c) return -1; RT_SETTLE(c); return launch_frames(c, first_frame, n_frames, Variant::Fast); }
+int rt_render_counting(rt_ctx* c, int first_frame, int n_frames) { if (!c) return -1; RT_SETTLE(c); return launch_frames(c, first_frame, n_frames, Variant::Counting); }
+int rt_render_frame_flat(rt_ctx* c, int frame_index) { if (!c) return -1; RT_SETTLE(c); return launch_frames(c, frame_index, 1, Variant::Flat); }
+
+// Queued submission.  rt_submit_frame returns at once; a worker thread of the library traces the queued frames in launches of whatever
+// has queued up while the previous launch ran (consecutive frame indices share a launch: frame-interleaved work items, one launch tail)
+// and accumulates them in submission order — the image equals rt_render's over the same frames, bit for bit.
+int rt_submit_frame(rt_ctx* c, int frame_index)
+{
+    if (!c) return -1;
+    if (!c->have_params) { RT_SETTLE(c); return fail(c, -2, "rt_set_params has not been called"); }
+    {
+        std::lock_guard<std::mutex> lk(c->q_mu);
+        if (c->q_rc) return c->q_rc;                    // a queued launch failed: rt_wait (or any other call) reports it
+        if (!c->q_started) { c->q_thread = std::thread(queue_worker, c); c->q_started = true; }
+        c->q_frames.push_back(frame_index);
+    }
+    c->q_cv.notify_one();
+    return 0;
+}
+int rt_wait(rt_ctx* c) { if (!c) return -1; RT_SETTLE(c); return 0; }
 
 int rt_reset_accum(rt_ctx* c)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     RT_HIP(c, hipSetDevice(c->device));
     if (c->target_pixels) {
         RT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, c->target_pixels * sizeof(float4), c->stream));
         RT_HIP(c, hipMemsetAsync(c->d_frame.p, 0, c->target_pixels * sizeof(float4), c->stream));
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
-    c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0;
+    c->stats.numRenderedFrames = 0; c->stats.totalKernelMs = 0; c->stats.queuedLaunches = 0;
     return 0;
 }
 
 int rt_write_accum(rt_ctx* c, const float* rgba, size_t n_floats, int frames_rendered)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (!rgba && n_floats) return fail(c, -2, "null source");
     if (frames_rendered < 0) return fail(c, -2, "frames_rendered < 0");
     if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
@@ -1140,13 +1241,14 @@ int rt_write_accum(rt_ctx* c, const float* rgba, size_t n_floats, int frames_ren
     return 0;
 }
 
-int rt_read_accum(rt_ctx* c, float* rgba, size_t n) { return read_target(c, true, rgba, n, false); }
-int rt_read_last_frame(rt_ctx* c, float* rgba, size_t n) { return read_target(c, false, rgba, n, false); }
-int rt_copy_accum_to_device(rt_ctx* c, void* dst, size_t n) { return read_target(c, true, (float*)dst, n, true); }
+int rt_read_accum(rt_ctx* c, float* rgba, size_t n) { if (!c) return -1; RT_SETTLE(c); return read_target(c, true, rgba, n, false); }
+int rt_read_last_frame(rt_ctx* c, float* rgba, size_t n) { if (!c) return -1; RT_SETTLE(c); return read_target(c, false, rgba, n, false); }
+int rt_copy_accum_to_device(rt_ctx* c, void* dst, size_t n) { if (!c) return -1; RT_SETTLE(c); return read_target(c, true, (float*)dst, n, true); }
 
 int rt_read_display(rt_ctx* c, uint32_t* rgba8, size_t n_pixels)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (!rgba8 && n_pixels) return fail(c, -2, "null destination");
     if (c->have_params) { int r = ensure_targets(c); if (r) return r; }
     if (n_pixels != c->target_pixels) return fail(c, -2, "expected %zu pixels (rows*width), got %zu", c->target_pixels, n_pixels);
@@ -1169,6 +1271,7 @@ int rt_read_display(rt_ctx* c, uint32_t* rgba8, size_t n_pixels)
 int rt_read_bvh(rt_ctx* c, void* nodes_f32, void* nodes_f16, size_t n_nodes)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (c->scene_dirty) return fail(c, -2, "the scene has not been built yet (render a frame first)");
     if (n_nodes != c->n_nodes) return fail(c, -2, "expected %zu nodes, got %zu", c->n_nodes, n_nodes);
     if (!n_nodes) return 0;
@@ -1182,6 +1285,7 @@ int rt_read_bvh(rt_ctx* c, void* nodes_f32, void* nodes_f16, size_t n_nodes)
 int rt_get_stats(rt_ctx* c, rt_stats* out)
 {
     if (!c) return -1;
+    RT_SETTLE(c);
     if (!out) return fail(c, -2, "null stats");
     *out = c->stats;
     return 0;
@@ -1200,6 +1304,8 @@ struct rt_multi {
     int width = 0, height = 0;
     bool have_params = false;
     DevBuf<float4> d_image, d_staging;          // on the first context's device: the assembled image, the incoming strips
+    DevBuf<uint32_t> d_display;                 // ... and its sRGB8 form (rt_multi_read_display)
+    std::vector<hipEvent_t> ev_strip;           // per context: its strip has arrived on the first device (recorded on the SOURCE context's stream)
     int max_rows = 0;
     double lastGatherMs = 0, lastSetupMs = 0;
     bool scene_dirty = true;                    // the first context holds an upload the others have not received yet
@@ -1261,6 +1367,11 @@ rt_multi* rt_multi_create(const int* devices, int n_devices)
     // direct peer copies between the first device and the others where the hardware allows it; a refusal only means that the runtime
     // stages the copy (rt_multi_get_info reports which it is, per context)
     m->peer.assign(n_devices, 1);
+    m->ev_strip.assign(n_devices, nullptr);
+    for (int i = 1; i < n_devices; ++i) {
+        (void)hipSetDevice(m->ctx[i]->device);
+        if (hipEventCreateWithFlags(&m->ev_strip[i], hipEventDisableTiming) != hipSuccess) { mfail(nullptr, -1, "rt_multi_create: event for context %d", i); rt_multi_destroy(m); return nullptr; }
+    }
     for (int i = 1; i < n_devices; ++i)
         if (m->ctx[i]->device != m->ctx[0]->device) {
             int ok = 1;
@@ -1281,7 +1392,9 @@ rt_multi* rt_multi_create(const int* devices, int n_devices)
 void rt_multi_destroy(rt_multi* m)
 {
     if (!m) return;
-    if (!m->ctx.empty()) { (void)hipSetDevice(m->ctx[0]->device); m->d_image.release(); m->d_staging.release(); }
+    for (size_t i = 0; i < m->ev_strip.size() && i < m->ctx.size(); ++i)
+        if (m->ev_strip[i]) { (void)hipSetDevice(m->ctx[i]->device); (void)hipEventDestroy(m->ev_strip[i]); }
+    if (!m->ctx.empty()) { (void)hipSetDevice(m->ctx[0]->device); m->d_image.release(); m->d_staging.release(); m->d_display.release(); }
     for (rt_ctx* c : m->ctx) rt_destroy(c);
     delete m;
 }
@@ -1311,9 +1424,29 @@ static int multi_upload(rt_multi* m, int r, const char* what)
     m->scene_dirty = true;
     return 0;
 }
-int rt_multi_upload_spheres(rt_multi* m, const rt_sphere* s, int n) { return m ? multi_upload(m, rt_upload_spheres(m->ctx[0], s, n), "rt_upload_spheres") : -1; }
+int rt_multi_upload_spheres(rt_multi* m, const rt_sphere* s, int n)
+{
+    if (!m) return -1;
+    // (a few records: every context takes them — with the geometry pipeline each context builds for itself, whichever upload comes first)
+    const int r = for_each_ctx(m, "rt_upload_spheres", [&](rt_ctx* c) { return rt_upload_spheres(c, s, n); });
+    if (!r && !m->ctx[0]->geom_local) m->scene_dirty = true;
+    return r;
+}
 int rt_multi_upload_triangles(rt_multi* m, const rt_triangle* t, int n) { return m ? multi_upload(m, rt_upload_triangles(m->ctx[0], t, n), "rt_upload_triangles") : -1; }
 int rt_multi_upload_meshinfo(rt_multi* m, const rt_meshinfo* mi, int n) { return m ? multi_upload(m, rt_upload_meshinfo(m->ctx[0], mi, n), "rt_upload_meshinfo") : -1; }
+// On-device geometry pipeline behind the handle.  Every context receives the local meshes once and the poses (40 B per mesh) per frame and
+// transforms, builds and refits ON ITS OWN DEVICE (the device build takes a few milliseconds): no geometry crosses xGMI per frame.
+int rt_multi_upload_local_meshes(rt_multi* m, const rt_triangle* tris, int n_tris, const rt_local_chunk* chunks, int n_chunks, int n_meshes)
+{
+    if (!m) return -1;
+    const int r = for_each_ctx(m, "rt_upload_local_meshes", [&](rt_ctx* c) { return rt_upload_local_meshes(c, tris, n_tris, chunks, n_chunks, n_meshes); });
+    if (!r) m->scene_dirty = false;             // nothing to fan out: every context holds the upload itself
+    return r;
+}
+int rt_multi_set_mesh_transforms(rt_multi* m, const rt_mesh_transform* xf, int n_meshes)
+{
+    return m ? for_each_ctx(m, "rt_set_mesh_transforms", [&](rt_ctx* c) { return rt_set_mesh_transforms(c, xf, n_meshes); }) : -1;
+}
 int rt_multi_set_option(rt_multi* m, const char* name, int value)
 {
     if (!m) return -1;
@@ -1330,6 +1463,11 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
     const int N = (int)m->ctx.size();
     bool stale = m->scene_dirty;
     for (rt_ctx* c : m->ctx) stale = stale || c->scene_dirty;       // (a builder option set through rt_multi_context(i), a context never filled)
+    if (m->ctx[0]->geom_local) {
+        // geometry pipeline: every context holds the local meshes and builds / refits on its own device, inside its rt_render below
+        for (rt_ctx* c : m->ctx) if (!c->geom_local) return mfail(m, -2, "rt_multi: some contexts hold local meshes and some do not (use the rt_multi_upload_* calls)");
+        stale = false; m->scene_dirty = false;
+    }
     if (stale) {
         // ---- scene change: the first context builds (one BVH build, one host -> device upload), the others receive the result
         const double t0 = now_ms();
@@ -1364,14 +1502,22 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
     for (rt_ctx* c : m->ctx) max_rows = std::max(max_rows, c->target_rows);
     M_HIP(m, m->d_image.ensure((size_t)W * H));
     M_HIP(m, m->d_staging.ensure((size_t)W * max_rows * (size_t)std::max(1, N - 1)));
-    M_HIP(m, hipEventRecord(root->evg0, root->stream));
+    M_HIP(m, hipStreamSynchronize(root->stream));           // (the staging area is allocated and idle: the sources may write)
+    const double tg0 = now_ms();
+    // every strip travels on ITS source context's stream — N - 1 independent transfers, each over its own xGMI link on a fully connected
+    // node, in flight together — and the first device's stream waits for the N - 1 arrival events before it scatters the rows
     for (int i = 1; i < N; ++i) {
         rt_ctx* c = m->ctx[i];
         if (c->target_pixels == 0) continue;
         float4* dst = m->d_staging.p + (size_t)(i - 1) * W * max_rows;
-        if (c->device == root->device && !root->opt_peer_copies) M_HIP(m, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, root->stream));
-        else M_HIP(m, hipMemcpyPeerAsync(dst, root->device, c->d_accum.p, c->device, c->target_pixels * sizeof(float4), root->stream));
+        M_HIP(m, hipSetDevice(c->device));
+        if (c->device == root->device && !root->opt_peer_copies) M_HIP(m, hipMemcpyAsync(dst, c->d_accum.p, c->target_pixels * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        else M_HIP(m, hipMemcpyPeerAsync(dst, root->device, c->d_accum.p, c->device, c->target_pixels * sizeof(float4), c->stream));
+        M_HIP(m, hipEventRecord(m->ev_strip[i], c->stream));
     }
+    M_HIP(m, hipSetDevice(root->device));
+    for (int i = 1; i < N; ++i)
+        if (m->ctx[i]->target_pixels != 0) M_HIP(m, hipStreamWaitEvent(root->stream, m->ev_strip[i], 0));
     for (int i = 0; i < N; ++i) {
         rt_ctx* c = m->ctx[i];
         if (c->target_pixels == 0) continue;
@@ -1380,11 +1526,53 @@ int rt_multi_render(rt_multi* m, int first_frame, int n_frames)
         hipLaunchKernelGGL(k_scatter_bands, dim3(std::max(1, std::min(64, (W * 8 + 255) / 256)), bands), dim3(256), 0, root->stream, src, m->d_image.p, W, H, i, N);
     }
     M_HIP(m, hipGetLastError());
-    M_HIP(m, hipEventRecord(root->evg1, root->stream));
     M_HIP(m, hipStreamSynchronize(root->stream));
-    float ms = 0.f;
-    M_HIP(m, hipEventElapsedTime(&ms, root->evg0, root->evg1));
-    m->lastGatherMs = ms;
+    m->lastGatherMs = now_ms() - tg0;           // host wall time from the first copy's submission to the assembled image (the copies run on N - 1 streams)
+    return 0;
+}
+
+// The display step for the assembled image (rt_read_display's twin): linear -> sRGB8 on the first device.
+int rt_multi_read_display(rt_multi* m, uint32_t* rgba8, size_t n_pixels)
+{
+    if (!m) return -1;
+    if (!rgba8 && n_pixels) return mfail(m, -2, "null destination");
+    if (n_pixels != (size_t)m->width * m->height) return mfail(m, -2, "expected %zu pixels (height*width), got %zu", (size_t)m->width * m->height, n_pixels);
+    if (!n_pixels) return 0;
+    if (!m->d_image.p) return mfail(m, -2, "nothing rendered yet");
+    rt_ctx* root = m->ctx[0];
+    M_HIP(m, hipSetDevice(root->device));
+    M_HIP(m, m->d_display.ensure(n_pixels));
+    const int grid = (int)std::min<size_t>((n_pixels + 255) / 256, (size_t)root->n_cu * 8);
+    hipLaunchKernelGGL(rtg::k_display_srgb8, dim3(grid), dim3(256), 0, root->stream, m->d_image.p, m->d_display.p, n_pixels);
+    M_HIP(m, hipGetLastError());
+    M_HIP(m, hipMemcpyAsync(rgba8, m->d_display.p, n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
+    M_HIP(m, hipStreamSynchronize(root->stream));
+    return 0;
+}
+
+// Restore a saved accumulation state (rt_write_accum's twin): the whole image goes in, every context takes the rows of its bands.
+int rt_multi_write_accum(rt_multi* m, const float* rgba, size_t n_floats, int frames_rendered)
+{
+    if (!m) return -1;
+    if (!m->have_params) return mfail(m, -2, "rt_multi_set_params has not been called");
+    if (!rgba && n_floats) return mfail(m, -2, "null source");
+    const int W = m->width, H = m->height, N = (int)m->ctx.size();
+    if (n_floats != (size_t)W * H * 4) return mfail(m, -2, "expected %zu floats (height*width*4), got %zu", (size_t)W * H * 4, n_floats);
+    std::vector<float> strip;
+    for (int i = 0; i < N; ++i) {
+        strip.clear();
+        for (int y0 = i * 8; y0 < H; y0 += N * 8) {
+            const int rows = std::min(8, H - y0);
+            strip.insert(strip.end(), rgba + (size_t)y0 * W * 4, rgba + (size_t)(y0 + rows) * W * 4);
+        }
+        const int r = rt_write_accum(m->ctx[i], strip.data(), strip.size(), frames_rendered);
+        if (r) return mfail(m, r, "rt_write_accum on context %d: %s", i, rt_last_error(m->ctx[i]));
+    }
+    // the assembled image follows, so that rt_multi_read_accum / rt_multi_read_display show the restored state before the next render
+    rt_ctx* root = m->ctx[0];
+    M_HIP(m, hipSetDevice(root->device));
+    M_HIP(m, m->d_image.ensure((size_t)W * H));
+    if (n_floats) M_HIP(m, hipMemcpy(m->d_image.p, rgba, n_floats * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 

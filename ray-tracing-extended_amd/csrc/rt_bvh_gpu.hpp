@@ -451,7 +451,7 @@ struct Result {
 // top_clusters: once the bottom-up rounds have left at most this many clusters, the rest of the tree — its top — is built by the
 // host's binned-SAH split search over the clusters' boxes (0: the rounds run down to 512 clusters and one workgroup finishes).
 inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, float origin_magnitude, int radius, Workspace& w,
-                        rtbvh::Node4* nodes, uint32_t* order, Result& out, uint32_t top_clusters = 0, const rtbvh::Tuning& tuning = rtbvh::Tuning())
+                        rtbvh::Node4* nodes, uint32_t* order, Result& out, uint32_t top_clusters, const rtbvh::Tuning& tuning)
 {
     const bool widen = radius > 0;              // a negative radius = that radius in every round (A/B of the schedule)
     radius = std::max(1, std::min(radius < 0 ? -radius : radius, kMaxRadius));

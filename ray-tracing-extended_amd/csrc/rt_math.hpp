@@ -177,6 +177,27 @@ __device__ __forceinline__ float log_(float x)
     return r;
 }
 __device__ __forceinline__ float log2_(float x) { return log_(x) * 1.44269504f; }
+// log_ for the values RandomValue returns — 0 and [2^-32, 1]: never NaN, negative, infinite or denormal.  The same operations in the
+// same order as log_ on the path those inputs take (so the same bits: tools/exactmath/verify.hip compares the two for every such
+// float); the special-case tests that can never fire are gone (a dozen VALU instructions per draw, three draws per hit).
+__device__ __forceinline__ float log_unit(float x)
+{
+    const uint32_t bits = f2u(x);
+    int e = (int)(bits >> 23) - 127;
+    float m = u2f((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float y = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f
+                   - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f - 1.6668057665e-1f) * f
+                + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    float r = f + y;
+    r = r + 0.693359375f * fe;
+    return x == 0.0f ? u2f(0xff800000u) : r;
+}
 
 // ---- 2^x ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float exp2_(float x)
@@ -261,7 +282,7 @@ __device__ __forceinline__ float random_normal(R& state)
 {
     const float TWO_PI = 2.0f * 3.1415926f;
     float theta = TWO_PI * random_value(state);
-    float rho = sqrt_(-2.0f * log_(random_value(state)));
+    float rho = sqrt_(-2.0f * log_unit(random_value(state)));        // (== log_ for every value RandomValue can return)
     return rho * cos_(theta);
 }
 // RayTracing.shader:216-223

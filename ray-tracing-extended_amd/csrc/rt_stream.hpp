@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
     uint32_t pxy = kNoPixel;            // current pixel: x | local row << 16 (the host keeps k_stream to targets of at most 65535 x 65535); kNoPixel: none
     uint32_t rng = 0u;                  // RT_RNG_PCG: the reference's stream, a serial chain through the pixel's samples and bounces.  RT_RNG_PHILOX keeps
                                         // no generator state at all: a draw is a function of (pixel, frame, sample, bounce) — rtm::PhiloxScope
-    int sample = 0, bounce = 0;         // PCG.  PHILOX keeps both in `sample` (sample | bounce << 16: the host refuses more than 65535 of either) — the
+    int sample = 0, bounce = 0;         // PCG.  PHILOX keeps both in `sample` (sample | bounce << 16: the host refuses more than 65000 samples or 32000 bounces, so the signed shift stays positive) — the
                                         // generator's temporaries need the register in the scatter code
     v3 total = rtm::mk(0.f, 0.f, 0.f), light = total, rayColour = total, o = total, d = total;
     RaySlabT<H> slab = make_slab<H>(rtm::mk(0.f, 0.f, 0.f), rtm::mk(1.f, 1.f, 1.f));

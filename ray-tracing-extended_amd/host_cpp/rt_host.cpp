@@ -304,18 +304,99 @@ static void check(rt_ctx* ctx, int rc, const char* what)
 {
     if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + rt_last_error(ctx));
 }
-
-void RayTracingManager::InitFrame(rt_ctx* ctx)
+static void mcheck(rt_multi* m, int rc, const char* what)
 {
-    SceneBuffers b = BuildBuffers();
-    check(ctx, rt_set_params(ctx, &b.params), "rt_set_params");
-    if (uploaded_to_ != ctx) {       // the reference re-uploads every frame (its TODO at RayTracedMesh.cs:37); once per context is enough here
-        check(ctx, rt_upload_spheres(ctx, b.spheres.data(), (int)b.spheres.size()), "rt_upload_spheres");
-        check(ctx, rt_upload_triangles(ctx, b.triangles.data(), (int)b.triangles.size()), "rt_upload_triangles");
-        check(ctx, rt_upload_meshinfo(ctx, b.meshInfo.data(), (int)b.meshInfo.size()), "rt_upload_meshinfo");
-        uploaded_to_ = ctx;
-    }
+    if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + rt_multi_last_error(m));
 }
+
+void RayTracingManager::CreateLocalMeshes(std::vector<rt_triangle>& tris, std::vector<rt_local_chunk>& chunks)
+{
+    tris.clear(); chunks.clear();
+    for (size_t m = 0; m < meshes.size(); ++m) {
+        RayTracedMesh& mesh = meshes[m];
+        (void)mesh.GetSubMeshes();              // splits the mesh when there is no cached result for it (RayTracedMesh.cs:24-29) and checks the limit
+        for (const MeshChunk& chunk : mesh.localChunks) {
+            rt_local_chunk c{};
+            c.firstTriangleIndex = (uint32_t)tris.size(); c.numTriangles = (uint32_t)chunk.triangles.size(); c.meshIndex = (uint32_t)m;
+            c.material = mesh.GetMaterial(chunk.subMeshIndex);
+            chunks.push_back(c);
+            tris.insert(tris.end(), chunk.triangles.begin(), chunk.triangles.end());
+        }
+    }
+    numMeshChunks = (int)chunks.size(); numTriangles = (int)tris.size();
+}
+
+std::vector<rt_mesh_transform> RayTracingManager::CreateTransforms() const
+{
+    std::vector<rt_mesh_transform> out(meshes.size());
+    for (size_t m = 0; m < meshes.size(); ++m) {
+        const Transform& t = meshes[m].transform;                                // RayTracedMesh.cs:38-40
+        out[m].position[0] = t.position.x; out[m].position[1] = t.position.y; out[m].position[2] = t.position.z;
+        out[m].rotation[0] = t.rotation.x; out[m].rotation[1] = t.rotation.y; out[m].rotation[2] = t.rotation.z; out[m].rotation[3] = t.rotation.w;
+        out[m].lossyScale[0] = t.lossyScale.x; out[m].lossyScale[1] = t.lossyScale.y; out[m].lossyScale[2] = t.lossyScale.z;
+    }
+    return out;
+}
+
+namespace {
+template <class T> bool same_bytes(const std::vector<T>& a, const std::vector<T>& b)
+{
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+}
+// the two handle kinds behind one InitFrame
+struct CtxApi {
+    void params(rt_ctx* c, const rt_params* p) const { check(c, rt_set_params(c, p), "rt_set_params"); }
+    void spheres(rt_ctx* c, const rt_sphere* s, int n) const { check(c, rt_upload_spheres(c, s, n), "rt_upload_spheres"); }
+    void triangles(rt_ctx* c, const rt_triangle* t, int n) const { check(c, rt_upload_triangles(c, t, n), "rt_upload_triangles"); }
+    void meshinfo(rt_ctx* c, const rt_meshinfo* m, int n) const { check(c, rt_upload_meshinfo(c, m, n), "rt_upload_meshinfo"); }
+    void local(rt_ctx* c, const rt_triangle* t, int nt, const rt_local_chunk* ch, int nc, int nm) const { check(c, rt_upload_local_meshes(c, t, nt, ch, nc, nm), "rt_upload_local_meshes"); }
+    void poses(rt_ctx* c, const rt_mesh_transform* x, int n) const { check(c, rt_set_mesh_transforms(c, x, n), "rt_set_mesh_transforms"); }
+};
+struct MultiApi {
+    void params(rt_multi* m, const rt_params* p) const { mcheck(m, rt_multi_set_params(m, p), "rt_multi_set_params"); }
+    void spheres(rt_multi* m, const rt_sphere* s, int n) const { mcheck(m, rt_multi_upload_spheres(m, s, n), "rt_multi_upload_spheres"); }
+    void triangles(rt_multi* m, const rt_triangle* t, int n) const { mcheck(m, rt_multi_upload_triangles(m, t, n), "rt_multi_upload_triangles"); }
+    void meshinfo(rt_multi* m, const rt_meshinfo* mi, int n) const { mcheck(m, rt_multi_upload_meshinfo(m, mi, n), "rt_multi_upload_meshinfo"); }
+    void local(rt_multi* m, const rt_triangle* t, int nt, const rt_local_chunk* ch, int nc, int nm) const { mcheck(m, rt_multi_upload_local_meshes(m, t, nt, ch, nc, nm), "rt_multi_upload_local_meshes"); }
+    void poses(rt_multi* m, const rt_mesh_transform* x, int n) const { mcheck(m, rt_multi_set_mesh_transforms(m, x, n), "rt_multi_set_mesh_transforms"); }
+};
+} // namespace
+
+// InitFrame (RayTracingManager.cs:95-109).  The reference rebuilds and re-uploads its three buffers every frame (its own TODO at
+// RayTracedMesh.cs:37); an upload makes the library rebuild its acceleration structure, so only what changed is sent again — and with
+// deviceGeometry nothing but the poses is sent per frame.
+template <class H, class Api> void RayTracingManager::InitFrameT(H* h, const Api& api)
+{
+    const bool first = uploaded_to_ != h;
+    SceneBuffers b;
+    std::memset(&b.params, 0, sizeof b.params);
+    b.params.width = width; b.params.height = height;
+    b.params.intersectMode = intersectMode; b.params.rngMode = RT_RNG_PCG;
+    UpdateCameraParams(b.params);
+    b.spheres = CreateSpheres();
+    SetShaderParams(b.params);
+    api.params(h, &b.params);
+    if (first || !same_bytes(b.spheres, sent_.spheres)) api.spheres(h, b.spheres.data(), (int)b.spheres.size());
+    if (deviceGeometry) {
+        std::vector<rt_triangle> lt; std::vector<rt_local_chunk> lc;
+        CreateLocalMeshes(lt, lc);
+        if (first || !sent_is_local_ || !same_bytes(lt, sent_local_) || !same_bytes(lc, sent_chunks_)) {
+            api.local(h, lt.data(), (int)lt.size(), lc.data(), (int)lc.size(), (int)meshes.size());
+            sent_local_.swap(lt); sent_chunks_.swap(lc); sent_is_local_ = true;
+        }
+        const std::vector<rt_mesh_transform> xf = CreateTransforms();
+        api.poses(h, xf.data(), (int)xf.size());
+    } else {
+        CreateMeshes(b.triangles, b.meshInfo);
+        if (first || sent_is_local_ || !same_bytes(b.triangles, sent_.triangles)) api.triangles(h, b.triangles.data(), (int)b.triangles.size());
+        if (first || sent_is_local_ || !same_bytes(b.meshInfo, sent_.meshInfo)) api.meshinfo(h, b.meshInfo.data(), (int)b.meshInfo.size());
+        sent_.triangles.swap(b.triangles); sent_.meshInfo.swap(b.meshInfo); sent_is_local_ = false;
+    }
+    sent_.spheres.swap(b.spheres);
+    uploaded_to_ = h;
+}
+
+void RayTracingManager::InitFrame(rt_ctx* ctx) { InitFrameT(ctx, CtxApi{}); }
 
 void RayTracingManager::Start(rt_ctx* ctx)
 {
@@ -334,22 +415,7 @@ void RayTracingManager::OnRenderImage(rt_ctx* ctx, int frames, std::vector<float
     }
 }
 
-static void mcheck(rt_multi* m, int rc, const char* what)
-{
-    if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + rt_multi_last_error(m));
-}
-
-void RayTracingManager::InitFrame(rt_multi* m)
-{
-    SceneBuffers b = BuildBuffers();
-    mcheck(m, rt_multi_set_params(m, &b.params), "rt_multi_set_params");
-    if (uploaded_to_ != m) {
-        mcheck(m, rt_multi_upload_spheres(m, b.spheres.data(), (int)b.spheres.size()), "rt_multi_upload_spheres");
-        mcheck(m, rt_multi_upload_triangles(m, b.triangles.data(), (int)b.triangles.size()), "rt_multi_upload_triangles");
-        mcheck(m, rt_multi_upload_meshinfo(m, b.meshInfo.data(), (int)b.meshInfo.size()), "rt_multi_upload_meshinfo");
-        uploaded_to_ = m;
-    }
-}
+void RayTracingManager::InitFrame(rt_multi* m) { InitFrameT(m, MultiApi{}); }
 
 void RayTracingManager::Start(rt_multi* m)
 {

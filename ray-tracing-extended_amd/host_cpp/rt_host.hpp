@@ -113,6 +113,9 @@ public:
     std::vector<RayTracedMesh> meshes;
     bool linearColourSpace = true;              // ProjectSettings.asset:50 — Material.SetColor converts sRGB -> linear
     int intersectMode = RT_INTERSECT_FLAT_CHUNKS;
+    // true: the on-device geometry pipeline (rt_upload_local_meshes / rt_set_mesh_transforms) — the local chunks go to the device once and
+    // a frame sends one pose per mesh; false: the reference's way, world-space triangles re-marshalled on the host (sent when they changed)
+    bool deviceGeometry = false;
     int serialisedNumMeshChunks = -1, serialisedNumTriangles = -1;   // written into the scene by the reference (:156-157)
 
     void OnValidate();                                                           // :196-203
@@ -121,6 +124,9 @@ public:
     std::vector<rt_sphere> CreateSpheres() const;                                // :167-187
     void CreateMeshes(std::vector<rt_triangle>& tris, std::vector<rt_meshinfo>& infos);   // :135-164
     SceneBuffers BuildBuffers();                                                 // InitFrame :95-109 without the device
+    // the geometry pipeline's inputs: every mesh's local chunks back to back (chunk.meshIndex = index into `meshes`) and one pose per mesh
+    void CreateLocalMeshes(std::vector<rt_triangle>& tris, std::vector<rt_local_chunk>& chunks);
+    std::vector<rt_mesh_transform> CreateTransforms() const;
     // With a device context: InitFrame + the two blits + frame counter (OnRenderImage :49-93).  Throws on C-ABI errors.
     void InitFrame(rt_ctx* ctx);
     void OnRenderImage(rt_ctx* ctx, int frames, std::vector<float>* resultTexture = nullptr);
@@ -135,6 +141,9 @@ public:
     void OnDisable() { uploaded_to_ = nullptr; }
 private:
     const void* uploaded_to_ = nullptr;         // the context (or rt_multi) that holds this manager's buffers
+    SceneBuffers sent_;                         // ... and what they hold (world-space path): only what changed is sent again
+    std::vector<rt_triangle> sent_local_; std::vector<rt_local_chunk> sent_chunks_; bool sent_is_local_ = false;
+    template <class H, class Api> void InitFrameT(H* h, const Api& api);
 };
 
 // Loads a reference scene (Unity YAML).  Throws std::runtime_error with a message on malformed input.

@@ -85,6 +85,42 @@ int rth_render_multi(void* hp, const int* devices, int n_contexts, int frames, f
     return rc;
 }
 
+// Animated scene through the compiled manager: `steps` times { every mesh is turned by the quaternion q4 (x, y, z, w: rotation = q * rotation)
+// and mesh i moves by shift3 * (i + 1); Start; OnRenderImage(frames_per_step) }, through one rt_ctx (n_contexts = 0) or an rt_multi of
+// n_contexts contexts, with or without the on-device geometry pipeline.  rgba = the last step's resultTexture.  What the reference does
+// every frame (RayTracedMesh.cs:36-84): with device_geometry only the poses travel.
+int rth_render_animated(void* hp, const int* devices, int n_contexts, int device_geometry, int steps, int frames_per_step, const float* q4,
+                        const float* shift3, float* rgba)
+{
+    auto* h = static_cast<Handle*>(hp);
+    rt_ctx* ctx = nullptr; rt_multi* m = nullptr;
+    if (n_contexts > 0) { m = rt_multi_create(devices, n_contexts); if (!m) { g_err = rt_multi_last_error(nullptr); return -1; } }
+    else { ctx = rt_create(devices ? devices[0] : 0); if (!ctx) { g_err = rt_last_error(nullptr); return -1; } }
+    int rc = 0;
+    try {
+        rthost::RayTracingManager mgr = h->mgr;
+        mgr.OnDisable();
+        mgr.deviceGeometry = device_geometry != 0;
+        std::vector<float> out;
+        for (int s = 0; s < steps; ++s) {
+            for (size_t i = 0; i < mgr.meshes.size(); ++i) {
+                const rthost::Quaternion q{ q4[0], q4[1], q4[2], q4[3] }, r = mgr.meshes[i].transform.rotation;
+                rthost::Quaternion& t = mgr.meshes[i].transform.rotation;         // q * r (UnityEngine Quaternion product)
+                t = { q.w * r.x + q.x * r.w + q.y * r.z - q.z * r.y, q.w * r.y + q.y * r.w + q.z * r.x - q.x * r.z,
+                      q.w * r.z + q.z * r.w + q.x * r.y - q.y * r.x, q.w * r.w - q.x * r.x - q.y * r.y - q.z * r.z };
+                const float k = (float)(i + 1);
+                mgr.meshes[i].transform.position.x += shift3[0] * k; mgr.meshes[i].transform.position.y += shift3[1] * k; mgr.meshes[i].transform.position.z += shift3[2] * k;
+            }
+            if (m) { mgr.Start(m); mgr.OnRenderImage(m, frames_per_step, &out); }
+            else { mgr.Start(ctx); mgr.OnRenderImage(ctx, frames_per_step, &out); }
+        }
+        std::memcpy(rgba, out.data(), out.size() * sizeof(float));
+    } catch (const std::exception& e) { g_err = e.what(); rc = -1; }
+    if (m) rt_multi_destroy(m);
+    if (ctx) rt_destroy(ctx);
+    return rc;
+}
+
 // ---- MeshSplitter / RayTracedMesh.GetSubMeshes through plain arrays (tests) --------------------------------------------
 // verts / normals: n_verts x 3 floats; indices: the index buffer; sub_ranges: n_sub x (indexStart, indexCount).
 // mode 0: MeshSplitter::CreateChunks(mesh) (local chunks);  mode 1: a RayTracedMesh without cached chunks and with that mesh as

@@ -25,6 +25,7 @@ def load_host_library():
         L.rth_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.rth_render.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
         L.rth_render_multi.argtypes = [c_void_p, POINTER(c_int), c_int, c_int, POINTER(c_float)]
+        L.rth_render_animated.argtypes = [c_void_p, POINTER(c_int), c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_float)]
         L.rth_split_mesh.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]
         L.rth_split_info.argtypes = [c_void_p, c_void_p, c_void_p]
         L.rth_split_triangles.argtypes = [c_void_p]
@@ -101,4 +102,18 @@ class CppScene:
         arr = (c_int * len(devices))(*devices)
         if self._L.rth_render_multi(self._h, arr, len(devices), frames, out.ctypes.data_as(POINTER(c_float))):
             raise RtError("OnRenderImage(rt_multi): " + self._L.rth_last_error().decode())
+        return out
+
+    def render_animated(self, steps: int, frames_per_step: int, q, shift, devices=(), device_geometry=False, device: int = 0) -> np.ndarray:
+        """`steps` pose changes (every mesh is turned by the quaternion q = x, y, z, w and mesh i moves by shift * (i + 1)), each followed by Start +
+        OnRenderImage(frames_per_step), through one rt_ctx (devices empty) or an rt_multi; device_geometry = the on-device pipeline (poses only
+        per step).  Returns the last image."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        devs = list(devices) if devices else [device]
+        arr = (c_int * len(devs))(*devs)
+        q4 = (c_float * 4)(*[float(v) for v in q])
+        sh = (c_float * 3)(*[float(v) for v in shift])
+        if self._L.rth_render_animated(self._h, arr, len(devices), 1 if device_geometry else 0, steps, frames_per_step, q4, sh,
+                                       out.ctypes.data_as(POINTER(c_float))):
+            raise RtError("render_animated: " + self._L.rth_last_error().decode())
         return out

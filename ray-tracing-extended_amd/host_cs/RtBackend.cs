@@ -26,8 +26,20 @@ namespace RtMi355x
         int width, height;
         Texture2D presentTexture;
         Array spheres = Array.Empty<byte>(), triangles = Array.Empty<byte>(), meshInfo = Array.Empty<byte>();
-        ulong sphereHash, triangleHash, meshInfoHash;
-        bool uploadedOnce;
+        // what each native handle (the game view's context or rt_multi, the scene view's preview context) has been sent: content that did not
+        // change is not sent again, for the preview either (an upload makes the library rebuild its acceleration structure)
+        sealed class Sent { public ulong spheres, triangles, meshInfo, local; public bool once; }
+        readonly Dictionary<IntPtr, Sent> sent = new Dictionary<IntPtr, Sent>();
+        ulong sphereHash, triangleHash, meshInfoHash;       // of the arrays above, computed when they are set
+        // on-device geometry pipeline (SetMeshObjects): local chunks once, poses per frame
+        bool localGeometry;
+        Triangle[] localTriangles = Array.Empty<Triangle>();
+        RtLocalChunk[] localChunks = Array.Empty<RtLocalChunk>();
+        RtMeshTransform[] meshTransforms = Array.Empty<RtMeshTransform>();
+        ulong localHash;
+        readonly List<MeshChunk[]> localChunkSources = new List<MeshChunk[]>();
+        public int NumMeshChunks { get; private set; }
+        public int NumTriangles { get; private set; }
 
         /// <param name="devices">HIP device ordinals; more than one tiles the frame across the GPUs (8-row bands + one gather)</param>
         public RtBackend(int[] devices)
@@ -83,11 +95,77 @@ namespace RtMi355x
         }
 
         // ---- the three structured buffers (the reference's own blittable structs: 80 / 72 / 96 bytes, passed as they are) --------
-        public void SetSpheres<T>(T[] items) where T : struct { spheres = items ?? (Array)Array.Empty<T>(); }
+        public void SetSpheres<T>(T[] items) where T : struct { spheres = items ?? (Array)Array.Empty<T>(); sphereHash = Hash(spheres); }
         public void SetMeshes<TTri, TInfo>(List<TTri> tris, List<TInfo> infos) where TTri : struct where TInfo : struct
         {
             triangles = tris != null ? tris.ToArray() : (Array)Array.Empty<TTri>();
             meshInfo = infos != null ? infos.ToArray() : (Array)Array.Empty<TInfo>();
+            triangleHash = Hash(triangles); meshInfoHash = Hash(meshInfo);
+            localGeometry = false;
+            NumTriangles = triangles.Length; NumMeshChunks = meshInfo.Length;
+        }
+
+        /// The on-device geometry pipeline: what the reference's own TODO asks for ("upload matrices to gpu to avoid having to contantly
+        /// upload all mesh data", RayTracedMesh.cs:37).  The local chunks of every RayTracedMesh go to the library once (again only when a
+        /// mesh object or its cached chunk array changes); a frame sends position / rotation / lossyScale per mesh — 40 bytes — and the
+        /// library transforms, re-bounds and refits on the GPU (on every GPU of an rt_multi: no geometry crosses xGMI per frame).
+        /// Needs RayTracedMesh.GetLocalChunks() (RayTracedMesh.cs.ed).  Returns false when there is nothing to trace through it.
+        public unsafe bool SetMeshObjects(RayTracedMesh[] meshObjects)
+        {
+            if (meshObjects == null) meshObjects = Array.Empty<RayTracedMesh>();
+            bool same = localGeometry && localChunkSources.Count == meshObjects.Length;
+            var sources = new List<MeshChunk[]>(meshObjects.Length);
+            for (int i = 0; i < meshObjects.Length; i++)
+            {
+                MeshChunk[] lc = meshObjects[i].GetLocalChunks();
+                sources.Add(lc);
+                same = same && ReferenceEquals(lc, localChunkSources[i]);
+            }
+            if (!same)
+            {
+                var tris = new List<Triangle>();
+                var chunks = new List<RtLocalChunk>();
+                for (int i = 0; i < meshObjects.Length; i++)
+                    foreach (MeshChunk chunk in sources[i])
+                    {
+                        RtLocalChunk c = new RtLocalChunk { firstTriangleIndex = (uint)tris.Count, numTriangles = (uint)chunk.triangles.Length, meshIndex = (uint)i };
+                        RayTracingMaterial mat = meshObjects[i].GetMaterial(chunk.subMeshIndex);
+                        UnsafeUtility.CopyStructureToPtr(ref mat, UnsafeUtility.AddressOf(ref c.material));      // both are the 64-byte material
+                        chunks.Add(c);
+                        tris.AddRange(chunk.triangles);
+                    }
+                localTriangles = tris.ToArray(); localChunks = chunks.ToArray();
+                localChunkSources.Clear(); localChunkSources.AddRange(sources);
+                localHash = Hash(localChunks) ^ (Hash(localTriangles) * 31UL);
+            }
+            else
+            {
+                // materials can change in the inspector without the chunk arrays changing: they are part of the upload
+                int k = 0;
+                for (int i = 0; i < meshObjects.Length; i++)
+                    foreach (MeshChunk chunk in sources[i])
+                    {
+                        RayTracingMaterial mat = meshObjects[i].GetMaterial(chunk.subMeshIndex);
+                        UnsafeUtility.CopyStructureToPtr(ref mat, UnsafeUtility.AddressOf(ref localChunks[k].material));
+                        k++;
+                    }
+                localHash = Hash(localChunks) ^ (Hash(localTriangles) * 31UL);
+            }
+            if (meshTransforms.Length != meshObjects.Length) meshTransforms = new RtMeshTransform[meshObjects.Length];
+            for (int i = 0; i < meshObjects.Length; i++)
+            {
+                Transform t = meshObjects[i].transform;
+                Vector3 pos = t.position, sc = t.lossyScale; Quaternion q = t.rotation;
+                fixed (RtMeshTransform* x = &meshTransforms[i])
+                {
+                    x->position[0] = pos.x; x->position[1] = pos.y; x->position[2] = pos.z;
+                    x->rotation[0] = q.x; x->rotation[1] = q.y; x->rotation[2] = q.z; x->rotation[3] = q.w;
+                    x->lossyScale[0] = sc.x; x->lossyScale[1] = sc.y; x->lossyScale[2] = sc.z;
+                }
+            }
+            localGeometry = true;
+            NumTriangles = localTriangles.Length; NumMeshChunks = localChunks.Length;
+            return true;
         }
 
         // ---- the blits ----------------------------------------------------------------------------------------------------
@@ -96,7 +174,7 @@ namespace RtMi355x
         public void RenderFrame(int frame)
         {
             EnsureContexts();
-            Push(ctx, multi, false);
+            Push(ctx, multi);
             if (multi != IntPtr.Zero) RtNative.CheckMulti(multi, RtNative.rt_multi_render(multi, frame, 1), "rt_multi_render");
             else RtNative.Check(ctx, RtNative.rt_render_frame(ctx, frame), "rt_render_frame");
         }
@@ -114,7 +192,7 @@ namespace RtMi355x
         public void RenderPreview(RenderTexture target, int frame)
         {
             if (previewCtx == IntPtr.Zero) previewCtx = Create(devices[0]);
-            Push(previewCtx, IntPtr.Zero, true);
+            Push(previewCtx, IntPtr.Zero);
             RtNative.Check(previewCtx, RtNative.rt_reset_accum(previewCtx), "rt_reset_accum");
             RtNative.Check(previewCtx, RtNative.rt_render_frame(previewCtx, frame), "rt_render_frame");
             UIntPtr n = (UIntPtr)((ulong)width * (ulong)height * 4UL);
@@ -145,9 +223,15 @@ namespace RtMi355x
 
         public void RestoreAccumulation(float[] rgba, int framesRendered)
         {
-            if (ctx == IntPtr.Zero) throw new InvalidOperationException("RestoreAccumulation needs the single-device context (render one frame first)");
+            EnsureContexts();
+            Push(ctx, multi);                   // (the targets must exist at the current size before a state can be written into them)
             GCHandle pin = GCHandle.Alloc(rgba, GCHandleType.Pinned);
-            try { RtNative.Check(ctx, RtNative.rt_write_accum(ctx, pin.AddrOfPinnedObject(), (UIntPtr)(ulong)rgba.LongLength, framesRendered), "rt_write_accum"); }
+            try
+            {
+                UIntPtr n = (UIntPtr)(ulong)rgba.LongLength;
+                if (multi != IntPtr.Zero) RtNative.CheckMulti(multi, RtNative.rt_multi_write_accum(multi, pin.AddrOfPinnedObject(), n, framesRendered), "rt_multi_write_accum");
+                else RtNative.Check(ctx, RtNative.rt_write_accum(ctx, pin.AddrOfPinnedObject(), n, framesRendered), "rt_write_accum");
+            }
             finally { pin.Free(); }
         }
 
@@ -166,7 +250,7 @@ namespace RtMi355x
             if (ctx != IntPtr.Zero) { RtNative.rt_destroy(ctx); ctx = IntPtr.Zero; }
             if (previewCtx != IntPtr.Zero) { RtNative.rt_destroy(previewCtx); previewCtx = IntPtr.Zero; }
             if (presentTexture != null) { UnityEngine.Object.DestroyImmediate(presentTexture); presentTexture = null; }
-            uploadedOnce = false;
+            sent.Clear();
         }
 
         // ---- internals ------------------------------------------------------------------------------------------------------
@@ -186,21 +270,52 @@ namespace RtMi355x
                 if (multi == IntPtr.Zero) throw new InvalidOperationException("rt_multi_create: " + RtNative.LastMultiError(IntPtr.Zero));
             }
             else ctx = Create(devices[0]);
-            uploadedOnce = false;
         }
 
         // The reference re-creates and re-uploads its three buffers every frame (its own TODO at RayTracedMesh.cs:37); the library
-        // rebuilds its acceleration structure on upload, so content that did not change is not sent again.
-        void Push(IntPtr c, IntPtr m, bool always)
+        // rebuilds its acceleration structure on upload, so a handle is only sent what it has not got yet (hashes per handle: the game
+        // view's and the scene view's preview context each keep their own record).
+        void Push(IntPtr c, IntPtr m)
         {
             if (m != IntPtr.Zero) RtNative.CheckMulti(m, RtNative.rt_multi_set_params(m, ref p), "rt_multi_set_params");
             else RtNative.Check(c, RtNative.rt_set_params(c, ref p), "rt_set_params");
-            ulong hs = Hash(spheres), ht = Hash(triangles), hm = Hash(meshInfo);
-            bool first = always || !uploadedOnce;
-            if (first || hs != sphereHash) Upload(c, m, RtNative.rt_upload_spheres, RtNative.rt_multi_upload_spheres, spheres, "rt_upload_spheres");
-            if (first || ht != triangleHash) Upload(c, m, RtNative.rt_upload_triangles, RtNative.rt_multi_upload_triangles, triangles, "rt_upload_triangles");
-            if (first || hm != meshInfoHash) Upload(c, m, RtNative.rt_upload_meshinfo, RtNative.rt_multi_upload_meshinfo, meshInfo, "rt_upload_meshinfo");
-            if (!always) { sphereHash = hs; triangleHash = ht; meshInfoHash = hm; uploadedOnce = true; }
+            IntPtr key = m != IntPtr.Zero ? m : c;
+            Sent had;
+            if (!sent.TryGetValue(key, out had)) { had = new Sent(); sent[key] = had; }
+            if (!had.once || had.spheres != sphereHash) Upload(c, m, RtNative.rt_upload_spheres, RtNative.rt_multi_upload_spheres, spheres, "rt_upload_spheres");
+            if (localGeometry)
+            {
+                if (!had.once || had.local != localHash || had.triangles != 0UL) UploadLocal(c, m);
+                GCHandle pin = meshTransforms.Length > 0 ? GCHandle.Alloc(meshTransforms, GCHandleType.Pinned) : default(GCHandle);
+                try
+                {
+                    IntPtr x = meshTransforms.Length > 0 ? pin.AddrOfPinnedObject() : IntPtr.Zero;
+                    if (m != IntPtr.Zero) RtNative.CheckMulti(m, RtNative.rt_multi_set_mesh_transforms(m, x, meshTransforms.Length), "rt_multi_set_mesh_transforms");
+                    else RtNative.Check(c, RtNative.rt_set_mesh_transforms(c, x, meshTransforms.Length), "rt_set_mesh_transforms");
+                }
+                finally { if (meshTransforms.Length > 0) pin.Free(); }
+                had.local = localHash; had.triangles = 0UL; had.meshInfo = 0UL;
+            }
+            else
+            {
+                if (!had.once || had.triangles != triangleHash || had.local != 0UL) Upload(c, m, RtNative.rt_upload_triangles, RtNative.rt_multi_upload_triangles, triangles, "rt_upload_triangles");
+                if (!had.once || had.meshInfo != meshInfoHash || had.local != 0UL) Upload(c, m, RtNative.rt_upload_meshinfo, RtNative.rt_multi_upload_meshinfo, meshInfo, "rt_upload_meshinfo");
+                had.triangles = triangleHash; had.meshInfo = meshInfoHash; had.local = 0UL;
+            }
+            had.spheres = sphereHash; had.once = true;
+        }
+
+        void UploadLocal(IntPtr c, IntPtr m)
+        {
+            GCHandle pt = localTriangles.Length > 0 ? GCHandle.Alloc(localTriangles, GCHandleType.Pinned) : default(GCHandle);
+            GCHandle pc = localChunks.Length > 0 ? GCHandle.Alloc(localChunks, GCHandleType.Pinned) : default(GCHandle);
+            try
+            {
+                IntPtr t = localTriangles.Length > 0 ? pt.AddrOfPinnedObject() : IntPtr.Zero, ch = localChunks.Length > 0 ? pc.AddrOfPinnedObject() : IntPtr.Zero;
+                if (m != IntPtr.Zero) RtNative.CheckMulti(m, RtNative.rt_multi_upload_local_meshes(m, t, localTriangles.Length, ch, localChunks.Length, meshTransforms.Length), "rt_multi_upload_local_meshes");
+                else RtNative.Check(c, RtNative.rt_upload_local_meshes(c, t, localTriangles.Length, ch, localChunks.Length, meshTransforms.Length), "rt_upload_local_meshes");
+            }
+            finally { if (localTriangles.Length > 0) pt.Free(); if (localChunks.Length > 0) pc.Free(); }
         }
 
         static void Upload(IntPtr c, IntPtr m, RtNative.UploadCall single, RtNative.UploadCall many, Array items, string what)
@@ -216,7 +331,7 @@ namespace RtMi355x
             finally { if (n > 0) pin.Free(); }
         }
 
-        static unsafe ulong Hash(Array items)           // FNV-1a over the array's bytes
+        static unsafe ulong Hash(Array items)           // FNV-1a over the array's content, 64 bits at a time
         {
             ulong h = 14695981039346656037UL;
             if (items.Length == 0) return h;
@@ -225,7 +340,10 @@ namespace RtMi355x
             try
             {
                 byte* b = (byte*)pin.AddrOfPinnedObject();
-                for (long i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211UL; }
+                long words = bytes / 8;
+                ulong* w = (ulong*)b;
+                for (long i = 0; i < words; i++) { h ^= w[i]; h *= 1099511628211UL; }              // (eight bytes per step: every element size here is a multiple of 8)
+                for (long i = words * 8; i < bytes; i++) { h ^= b[i]; h *= 1099511628211UL; }
             }
             finally { pin.Free(); }
             return h;

@@ -128,7 +128,7 @@ namespace RtMi355x
         public int bvhRebuilds;
         public int bvhRepads;
         public int lastSampleLanes;
-        public int _reserved;
+        public int queuedLaunches;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -171,6 +171,8 @@ namespace RtMi355x
         [DllImport(Lib)] public static extern int rt_render_counting(IntPtr ctx, int firstFrame, int nFrames);
         [DllImport(Lib)] public static extern int rt_render_frame_flat(IntPtr ctx, int frameIndex);
         [DllImport(Lib)] public static extern int rt_reset_accum(IntPtr ctx);
+        [DllImport(Lib)] public static extern int rt_submit_frame(IntPtr ctx, int frameIndex);
+        [DllImport(Lib)] public static extern int rt_wait(IntPtr ctx);
         // ---- read-back / restore
         [DllImport(Lib)] public static extern int rt_read_accum(IntPtr ctx, IntPtr rgba, UIntPtr nFloats);
         [DllImport(Lib)] public static extern int rt_read_last_frame(IntPtr ctx, IntPtr rgba, UIntPtr nFloats);
@@ -198,6 +200,10 @@ namespace RtMi355x
         [DllImport(Lib)] public static extern int rt_multi_read_accum(IntPtr multi, IntPtr rgba, UIntPtr nFloats);
         [DllImport(Lib)] public static extern int rt_multi_get_stats(IntPtr multi, out RtStats stats, out double gatherMs);
         [DllImport(Lib)] public static extern int rt_multi_get_info(IntPtr multi, out RtMultiInfo info);
+        [DllImport(Lib)] public static extern int rt_multi_upload_local_meshes(IntPtr multi, IntPtr localTris, int nTris, IntPtr chunks, int nChunks, int nMeshes);
+        [DllImport(Lib)] public static extern int rt_multi_set_mesh_transforms(IntPtr multi, IntPtr transforms, int nMeshes);
+        [DllImport(Lib)] public static extern int rt_multi_read_display(IntPtr multi, IntPtr rgba8, UIntPtr nPixels);
+        [DllImport(Lib)] public static extern int rt_multi_write_accum(IntPtr multi, IntPtr rgba, UIntPtr nFloats, int framesRendered);
 
         // ---- helpers --------------------------------------------------------------------------------------------------
         public static string LastError(IntPtr ctx) { return Marshal.PtrToStringAnsi(rt_last_error(ctx)) ?? ""; }

@@ -122,7 +122,7 @@ def test_manager_patch_applies_to_the_reference_and_keeps_its_serialised_surface
     assert re.search(r"public class RayTracingManager\s*:\s*MonoBehaviour", text) and "public const int TriangleLimit = 1500;" in text
     for field in ("maxBounceCount", "numRaysPerPixel", "defocusStrength", "divergeStrength", "focusDistance", "environmentSettings",
                   "useShaderInSceneView", "rayTracingShader", "accumulateShader", "numRenderedFrames", "numMeshChunks", "numTriangles",
-                  "devices", "literalChunkCull", "philox"):
+                  "devices", "literalChunkCull", "philox", "deviceGeometry"):
         assert re.search(r"\[SerializeField[^\]]*\]\s*[\w\[\]]+\s+" + field + r"\b", text), field
     assert text.count("{") == text.count("}")
     for gone in ("rayTracingMaterial", "accumulateMaterial", "ComputeBuffer", "ShaderHelper", "RenderTexture.GetTemporary"):
@@ -137,3 +137,29 @@ def test_manager_patch_applies_to_the_reference_and_keeps_its_serialised_surface
     ref_lines = {l.strip() for l in open(ref).read().splitlines() if len(l.strip()) > 12}
     new_lines = [l.strip() for l in script if not re.fullmatch(r"\d+(,\d+)?[acd]\n|\.\n", l)]
     assert not [l for l in new_lines if l in ref_lines]
+    # the on-device geometry pipeline is reached from CreateMeshes, before the host-side transform loop
+    assert text.index("backend.SetMeshObjects(meshObjects)") < text.index("GetSubMeshes()")
+
+
+def test_mesh_component_patch_adds_the_local_chunk_accessor():
+    """host_cs/RayTracedMesh.cs.ed: one added method, GetLocalChunks(), which RtBackend.SetMeshObjects calls; the component's serialised
+    fields and its own methods stay as they are, and the script holds no line of the reference."""
+    ref = "/root/reference/Assets/Scripts/Render Types/RayTracedMesh.cs"
+    if not os.path.exists(ref):
+        pytest.skip("the reference project is not on this machine")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import apply_ed
+    script = open(os.path.join(CS, "RayTracedMesh.cs.ed")).read().splitlines(True)
+    before = open(ref, newline="").read().replace("\r\n", "\n")
+    text = "".join(apply_ed.apply_ed(before.splitlines(True), script))
+    assert text.count("{") == text.count("}")
+    assert "public MeshChunk[] GetLocalChunks()" in text and text.index("public MeshChunk[] GetSubMeshes()") < text.index("GetLocalChunks()")
+    for kept in ("[SerializeField] MeshChunk[] localChunks;", "void UpdateWorldChunkFromLocal(", "public RayTracingMaterial GetMaterial(int subMeshIndex)"):
+        assert kept in text, kept
+    removed = [l for l in before.splitlines() if l.strip() and l not in text.splitlines()]
+    assert not removed, removed
+    ref_lines = {l.strip() for l in before.splitlines() if len(l.strip()) > 12}
+    new_lines = [l.strip() for l in script if not re.fullmatch(r"\d+(,\d+)?[acd]\n|\.\n", l)]
+    assert not [l for l in new_lines if l in ref_lines]
+    backend = open(os.path.join(CS, "RtBackend.cs")).read()
+    assert ".GetLocalChunks()" in backend

@@ -281,3 +281,30 @@ def test_camera_drifting_away_from_the_geometry_widens_the_padding_without_a_reb
             dist *= 1.3
         assert 1 <= st["bvhRepads"] - repads0 <= 3, st["bvhRepads"] - repads0
     tracer.set_option("kernel", 0)
+
+
+def test_philox_mode_at_the_largest_accepted_bounce_count(rtx, oracle, tracer):
+    """A closed room of white mirrors keeps every path alive (Russian roulette's p = 1: Trace :338-342), so only the loop bound (:305)
+    ends it.  The Philox instantiation keeps sample and bounce in one register (bounce in the high half); the host accepts up to 32000
+    bounces so that the packed counter never reaches the sign bit.  8x8 pixels x 1 ray x 32001 casts: image and ray count == oracle twin;
+    one bounce more is refused."""
+    m = rtx.scenes.config2(8, 8)
+    for s in m.spheres:
+        s.material.colour = (1, 1, 1, 1); s.material.specularColour = (1, 1, 1, 1); s.material.emissionStrength = 0.0
+        s.material.specularProbability = 1.0; s.material.smoothness = 1.0; s.material.flag = 0
+    m.numRaysPerPixel, m.maxBounceCount = 1, 32000
+    params, spheres, tris, infos = m.build_buffers()
+    params = params.copy(); params["rngMode"] = 1
+    b = (params, spheres, tris, infos)
+    acc, last = run_gpu(tracer, b, 0, 1, kernel=1)
+    st = tracer.stats()
+    want, want_last, cnt = oracle.render(*b, 0, 1)
+    assert cnt["rays"] > 60 * 32001                       # nearly every path ran into the bound
+    assert st["rays"] == cnt["rays"]
+    assert_bitwise(acc, want, "philox, 32000 bounces")
+    params["maxBounceCount"] = 32001
+    tracer.set_params(params)
+    with pytest.raises(rtx.RtError):
+        tracer.render(0, 1)
+    params["maxBounceCount"] = 3
+    tracer.set_params(params)

@@ -156,3 +156,54 @@ def test_bench_line_through_rccl_with_a_process_group_of_one():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["comm"]["backend"] == "nccl" and line["comm"]["world_seen"] == 1 and line["n_gpus"] == 1
     assert line["value"] > 0 and line["per_rank"]["rays"][0] > 0 and "RCCL gather" in line["config"]["decomposition"]
+
+
+@pytest.mark.parametrize("n,peer", [(1, 0), (3, 0), (8, 0), (3, 1)])
+def test_moving_meshes_through_rt_multi(rtx, oracle, tracer, n, peer):
+    """The reference moves meshes every frame (RayTracedMesh.cs:36-84, RayTracingManager.cs:135-164).  Through rt_multi: the local meshes go
+    to every context once, then only poses (40 B per mesh) — every context transforms, builds and refits its own copy.  After each of two
+    pose changes the assembled image == one context through the same pipeline == a fresh host-transformed upload == the oracle; the
+    display step and a saved / restored accumulation state go through the handle as well."""
+    h = rtx.host
+    mgr = rtx.scenes.mesh_test_scene(88, 61)
+    params, spheres, _, _ = mgr.build_buffers()
+    with rtx.MultiTracer([0] * n) as mt:
+        mt.set_option("kernel", 1); mt.set_option("peer_copies", peer)
+        mt.set_params(params)
+        mt.upload(spheres=spheres)
+        mt.upload_local_meshes(*mgr.build_local_buffers(), len(mgr.meshes))
+        for step in range(3):
+            if step:
+                for i, mesh in enumerate(mgr.meshes[1:]):
+                    a = 0.3 * (i + 1) + 0.9 * step
+                    q = h.quat_mul((0.0, np.sin(a / 2), 0.0, np.cos(a / 2)), mesh.transform.rotation)
+                    mesh.transform = h.Transform(position=mesh.transform.position + np.float32([0.25 * step, 0.1 * i, -0.15]),
+                                                 rotation=q, lossyScale=mesh.transform.lossyScale * np.float32(1.07))
+            mt.set_mesh_transforms(mgr.build_transforms())
+            mt.reset_accum()
+            mt.render(2, 3)
+            got = mt.read_accum()
+            b = mgr.build_buffers()
+            want, _, cnt = oracle.render(*b, 2, 3)
+            assert_bitwise(got, want, f"rt_multi x{n} (peer_copies {peer}), moving meshes, step {step}: vs oracle")
+            assert mt.stats()["rays"] == cnt["rays"]
+            assert np.array_equal(mt.read_display(), oracle.display_srgb8(got))
+        info = mt.info()
+        assert info["bvhBuilds"] == n                     # one device build per context, then refits only
+        # save / restore through the handle: 3 frames, unrelated work, restore, 2 more == 5 frames in one go
+        saved = got.copy()
+        mt.reset_accum(); mt.render(40, 1)
+        mt.write_accum(saved, 5)                          # (frames 2..4 were rendered: the next frame index is 5)
+        assert_bitwise(mt.read_accum(), saved, "restored state is visible before the next render")
+        mt.render(5, 2)
+        resumed = mt.read_accum()
+        mt.reset_accum(); mt.render(2, 5)
+        assert_bitwise(resumed, mt.read_accum(), f"rt_multi x{n}: resumed render vs uninterrupted")
+        with pytest.raises(rtx.RtError):
+            mt.write_accum(saved[:-1], 3)
+    # one context through the same pipeline
+    tracer.set_option("kernel", 1)
+    tracer.set_rows(0, int(params["height"])); tracer.set_params(params); tracer.upload(spheres=spheres)
+    tracer.upload_local_meshes(*mgr.build_local_buffers(), len(mgr.meshes)); tracer.set_mesh_transforms(mgr.build_transforms())
+    tracer.reset_accum(); tracer.render(2, 3)
+    assert_bitwise(got, tracer.read_accum(), f"rt_multi x{n} vs one context, device geometry")

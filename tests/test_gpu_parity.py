@@ -467,3 +467,60 @@ def test_f16_boxes_contain_the_f32_boxes(rtx, tracer, scene):
     assert ((maxs16 - maxs32)[u3] <= np.broadcast_to(slack, mins32.shape)[u3]).all()
     halves = f16[:, :24].copy().view(np.uint16)
     assert not (((halves & 0x7C00) == 0) & ((halves & 0x03FF) != 0)).any(), "an f16 denormal was stored"
+
+
+@pytest.mark.parametrize("philox", [0, 1])
+def test_queued_frame_submission_equals_rt_render(rtx, oracle, tracer, philox):
+    """rt_submit_frame / rt_wait: a host that hands frames in one at a time — the reference's OnRenderImage pattern, RayTracingManager.cs:74-91
+    — gets them traced by the library's worker thread in launches of whatever has queued up, accumulated in submission order.  21 frames
+    (sun at 200x: the clamped running average is order-sensitive) == rt_render(0, 21) == the oracle; fewer launches than frames; reading in
+    the middle is safe; a gap in the frame indices only splits the launch; queue_depth = 1 degenerates to frame by frame."""
+    params, spheres, tris, infos = rtx.scenes.config1(72, 40).build_buffers()
+    params = params.copy(); params["rngMode"] = philox
+    b = (params, spheres, tris, infos)
+    ref, ref_last = run_gpu(tracer, b, 0, 21, kernel=-1)
+    want, want_last, _ = oracle.render(*b, 0, 21)
+    assert_bitwise(ref, want, "rt_render")
+    tracer.reset_accum()
+    for f in range(9):
+        tracer.submit_frame(f)
+    part = tracer.read_accum()                       # every other call waits for the queue first
+    assert tracer.stats()["numRenderedFrames"] == 9
+    for f in range(9, 21):
+        tracer.submit_frame(f)
+    tracer.wait()
+    st = tracer.stats()
+    assert st["numRenderedFrames"] == 21 and 2 <= st["queuedLaunches"] <= 21
+    assert_bitwise(tracer.read_accum(), want, "queued submission, accum")
+    assert_bitwise(tracer.read_last_frame(), want_last, "queued submission, last frame")
+    want9, _, _ = oracle.render(*b, 0, 9)
+    assert_bitwise(part, want9, "queued submission, read after nine frames")
+    # frame by frame through the queue, and a gap in the indices (frames 0..4 then 30..33: two runs, accumulated in that order)
+    tracer.set_option("queue_depth", 1)
+    try:
+        tracer.reset_accum()
+        for f in list(range(5)) + list(range(30, 34)):
+            tracer.submit_frame(f)
+        tracer.wait()
+        assert tracer.stats()["queuedLaunches"] == 9
+        gap = tracer.read_accum()
+    finally:
+        tracer.set_option("queue_depth", 64)
+    tracer.reset_accum(); tracer.render(0, 5); tracer.render(30, 4)
+    assert_bitwise(gap, tracer.read_accum(), "queued submission with a gap == two rt_render calls")
+
+
+def test_queued_submission_reports_the_error_of_a_queued_launch(rtx, tracer):
+    """A launch that fails inside the worker (here: a row strip outside the image) is reported by the next call that waits, once; the
+    context works again afterwards."""
+    b = rtx.scenes.config1(32, 24).build_buffers()
+    run_gpu(tracer, b, 0, 1)
+    tracer.set_rows(20, 10)                          # rows [20, 30) of a 24-row image: checked at launch time
+    tracer.submit_frame(0); tracer.submit_frame(1)
+    with pytest.raises(rtx.RtError, match="queued frame"):
+        tracer.wait()
+    tracer.set_rows(0, 24)
+    tracer.reset_accum()
+    tracer.submit_frame(0)
+    tracer.wait()
+    assert tracer.stats()["numRenderedFrames"] == 1

@@ -91,6 +91,36 @@ def test_cpp_manager_renders_the_same_image(rtx, tracer, tmp_path):
     assert_bitwise(got3, want, "C++ host through rt_multi x3")
 
 
+def test_cpp_manager_animates_through_the_device_geometry_pipeline(rtx, oracle, tmp_path):
+    """The reference moves its meshes every frame (RayTracedMesh.cs:36-84).  The compiled manager, three pose changes in a row: the
+    host path (world triangles re-marshalled and re-sent when they changed) == the on-device pipeline on one context (poses only) ==
+    the same through an rt_multi of three contexts (rt_multi_upload_local_meshes / rt_multi_set_mesh_transforms) == the Python host's
+    marshal of the final pose through the oracle."""
+    from rtx_amd import unity_scene
+    from rtx_amd.host_cpp_binding import CppScene
+    h = rtx.host
+    mgr = rtx.scenes.mesh_test_scene(88, 56)
+    path = str(tmp_path / "scene.unity")
+    unity_scene.save_unity_scene(mgr, path)
+    cpp = CppScene(path, 88, 56)
+    steps, shift = 3, np.float32([0.125, 0.0625, -0.25])
+    q = np.float32([0.0, np.sin(0.2), 0.0, np.cos(0.2)])        # (float32 values handed to both hosts: no trigonometry on either side)
+    host_path = cpp.render_animated(steps, 2, q, shift)
+    dev_one = cpp.render_animated(steps, 2, q, shift, device_geometry=True)
+    dev_multi = cpp.render_animated(steps, 2, q, shift, devices=[0, 0, 0], device_geometry=True)
+    host_multi = cpp.render_animated(steps, 2, q, shift, devices=[0, 0])
+    cpp.close()
+    for _ in range(steps):                       # the same poses in the Python host (float32, UnityEngine's quaternion product)
+        for i, mesh in enumerate(mgr.meshes):
+            mesh.transform = h.Transform(position=mesh.transform.position + shift * np.float32(i + 1), rotation=h.quat_mul(q, mesh.transform.rotation),
+                                         lossyScale=mesh.transform.lossyScale)
+    want, _, _ = oracle.render(*mgr.build_buffers(), 0, 2)
+    assert_bitwise(host_path, want, "C++ manager, animated, host path vs oracle")
+    assert_bitwise(dev_one, want, "C++ manager, animated, device geometry")
+    assert_bitwise(dev_multi, want, "C++ manager, animated, device geometry through rt_multi x3")
+    assert_bitwise(host_multi, want, "C++ manager, animated, host path through rt_multi x2")
+
+
 def test_config5_million_triangles_crop_vs_oracle(rtx, oracle, tracer):
     """configs[4]: 1,004,364 triangles, depth of field on — a 24x6 window of the 320x180 image against the oracle's flat
     loop over all 74k chunks (the deep BVH must return the reference's closest hit)."""

@@ -1,6 +1,7 @@
 // verify.hip — verification on gfx950 of the short correctly-rounded sequences in csrc/rt_math.hpp against the compiler's IEEE
 // operations:  rtm::rcp_ and rtm::sqrt_ on EVERY float32 bit pattern, rtm::div_mid on 4e10 random and structured quotients inside
-// its guard, rtm::normalize on 2e10 random vectors (components from 0 / -0 / denormal to 2^70, NaN and inf included).
+// its guard, rtm::normalize on 2e10 random vectors (components from 0 / -0 / denormal to 2^70, NaN and inf included), and rtm::log_unit
+// against rtm::log_ on every value RandomValue can return.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-gpu-flush-denormals-to-zero -fhip-fp32-correctly-rounded-divide-sqrt
 //        -fno-fast-math -fno-slp-vectorize verify.hip -o verify          (the library's own flags)
 #include <hip/hip_runtime.h>
@@ -18,6 +19,8 @@ __global__ void k_unary(unsigned long long* bad, uint32_t* first_bad)
         if (!same(rcp_(x), 1.0f / x)) { if (atomicAdd(&bad[0], 1ull) == 0) first_bad[0] = (uint32_t)i; }
         if (!same(sqrt_(x), __builtin_sqrtf(x))) { if (atomicAdd(&bad[1], 1ull) == 0) first_bad[1] = (uint32_t)i; }
         if (x >= 1e-6f && x <= 0x1p100f && !same(rcp_mid(x), 1.0f / x)) atomicAdd(&bad[0], 1ull);     // the RayTriangle use
+        // log_unit == log_ on everything RandomValue returns: +0 and [2^-32, 1]
+        if (((uint32_t)i == 0u || (x >= 0x1p-32f && x <= 1.0f)) && !same(log_unit(x), log_(x))) { if (atomicAdd(&bad[4], 1ull) == 0) first_bad[7] = (uint32_t)i; }
     }
 }
 __device__ __forceinline__ uint32_t pcg(uint32_t& s) { s = s * 747796405u + 2891336453u; uint32_t r = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u; return (r >> 22) ^ r; }
@@ -80,5 +83,6 @@ int main()
     printf("sqrt_     mismatches over all 2^32 inputs: %llu (first bad input 0x%08x)\n", h[1], hf[1]);
     printf("div_mid   mismatches: %llu of %llu quotients inside the guard (first bad a=0x%08x b=0x%08x)\n", h[2], h[5], hf[2], hf[3]);
     printf("normalize mismatches: %llu of %.3g vectors (first bad 0x%08x 0x%08x 0x%08x)\n", h[3], 4096.0 * 256 * nrounds, hf[4], hf[5], hf[6]);
-    return (h[0] | h[1] | h[2] | h[3]) ? 1 : 0;
+    printf("log_unit  mismatches against log_ over +0 and every float in [2^-32, 1]: %llu (first bad input 0x%08x)\n", h[4], hf[7]);
+    return (h[0] | h[1] | h[2] | h[3] | h[4]) ? 1 : 0;
 }
