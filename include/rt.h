@@ -164,6 +164,10 @@ typedef struct rt_stats {
                                            boxes were padded for: refit of the existing tree, no rebuild, no re-upload)   */
     int32_t  lastSampleLanes;           /* Philox mode: lanes of a wave that shared a pixel's samples in the last launch (16, 4 or 1) */
     int32_t  queuedLaunches;            /* launches the rt_submit_frame queue has made since rt_reset_accum                */
+    uint64_t schedExecs[6];             /* rt_render_counting, k_stream: wave-level executions of its scheduling regions — 0 SHADE passes, */
+                                        /* 1 leaf phases, 2 traversal bursts, 3 outer iterations of the bursts, 4 node-loop iterations,   */
+                                        /* 5 group fetches (with phaseExecs and the regions' static instruction counts: the launch's     */
+                                        /* VALU instruction count without a profiler, bench.py roofline.valu_model)                      */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

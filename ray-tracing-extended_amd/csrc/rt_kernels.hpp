@@ -62,7 +62,7 @@ struct FrameArgs {
     float4* accum;              // [nrows*W] resultTexture
     float* park;                // k_stream, Philox mode: per wave [items of a group][3][64] sub-stream sums waiting for the estimator's tree; else null
     unsigned int* tile_counter;
-    unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5]
+    unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5], sched[6]
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -98,8 +98,19 @@ __device__ __forceinline__ unsigned long long ballot_(bool pred) { return __buil
 // lowered through a VGPR again)
 __device__ __forceinline__ unsigned long long ballot2_(bool a, bool b) { return __builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b); }
 
-struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; };
-constexpr int kNumCounters = 15;
+// sched[k] (k_stream, counting build): wave-level executions of the scheduling regions — 0 SHADE passes, 1 leaf phases, 2 traversal bursts,
+// 3 iterations of a burst's outer loop, 4 iterations of its node loop, 5 group fetches.  With the static VALU count of every region
+// (tools/static_valu.py, from the code object's assembly) they give the launch's VALU instruction count without a profiler pass.
+struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; uint32_t sched[6]; };
+constexpr int kNumCounters = 21;
+
+// Region markers for tools/static_valu.py: an assembler comment in a side-effect asm statement (it assembles to nothing).  Only the -S
+// compile of that tool defines RT_MARKERS; the product library is built without them.
+#ifdef RT_MARKERS
+#define RT_MARK(TEXT) asm volatile("; RTMARK " TEXT)
+#else
+#define RT_MARK(TEXT) do { } while (0)
+#endif
 
 template <bool COUNT>
 __device__ __forceinline__ void phase_tick(Counters& cnt, int k)
@@ -683,6 +694,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
     {
         unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
         for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
+        for (int k = 0; k < 6; ++k) v[15 + k] = cnt.sched[k];
         for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

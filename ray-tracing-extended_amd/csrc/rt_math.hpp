@@ -52,7 +52,7 @@ __device__ __forceinline__ float sqrt_mid(float x)
 }
 // The IEEE fallbacks must stay behind real branches: both sides are speculatable, and if-converted they would run for every
 // lane next to the short sequence.  An (empty) volatile asm cannot be speculated, so the block it sits in stays a block.
-#define RT_COLD_PATH() asm volatile("")
+#define RT_COLD_PATH() asm volatile("; RTCOLD")       /* (the comment marks the block for tools/static_valu.py; it assembles to nothing) */
 __device__ __forceinline__ float rcp_(float x)                                                         // == 1.0f / x
 {
     float r = rcp_mid(x);

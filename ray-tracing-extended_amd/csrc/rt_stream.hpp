@@ -207,6 +207,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
         const int nTrav = __popcll(ballot_(mode == kModeTrav)), nShade = __popcll(ballot_(mode == kModeShade));
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
+            RT_MARK("begin fetch");
+            if (COUNT && lane == 0) cnt.sched[5]++;
             // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
             const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             }
             next_unit = 0;
             if (take_units(F, A, true)) { fresh = true; mode = kModeShade; }
+            RT_MARK("end fetch");
             continue;
         }
 
@@ -304,6 +307,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             // shading waves fill the gaps: +4.5 % / +3.3 % on the two triangle workloads (0/0: 12.86, trav 1 / shade 0: 13.44,
             // trav 0 / shade 1: 12.91, node loop 2 / leaves 1 / shade 0: 13.44 Grays/s).
             __builtin_amdgcn_s_setprio(0);
+            RT_MARK("begin shade");
+            if (COUNT && lane == 0) cnt.sched[0]++;
             const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const DeviceScene& S = KA.S; const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
             const rt_params& p = F.p;
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                 if (live) {
                     if (best.id != kNone) {
                         // ---- hit: Trace :309-343
+                        RT_MARK("begin hit");
                         phase_tick<COUNT>(cnt, 2);
                         if (COUNT) cnt.hits++;
                         const v3 hitPoint = o + d * best.t;
@@ -370,12 +376,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         }
                         if constexpr (PHILOX) { sample += 0x10000; if ((sample >> 16) > p.maxBounceCount) path_done = true; }
                         else { ++bounce; if (bounce > p.maxBounceCount) path_done = true; }   // loop bound :305
+                        RT_MARK("end hit");
                     } else {
+                        RT_MARK("begin env");
 #if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 3);
 #endif
                         light = light + environment_light(p, d) * rayColour;           // :346-347
                         path_done = true;
+                        RT_MARK("end env");
                     }
                     if (path_done) {
                         total = total + light;                                         // :384
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                 if (mode == kModeShade) {
                     if (need_ray) {
                         // ---- frag :364-382
+                        RT_MARK("begin camera");
 #if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 4);
 #endif
@@ -468,6 +478,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         } else camera_ray(p, cam, rng, o, d, F.fixed_origin != 0);
                         if constexpr (PHILOX) sample &= 0xFFFF; else bounce = 0;
                         rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
+                        RT_MARK("end camera");
                     }
                     {
                         // ---- new closest-hit query: CalculateRayCollision :256-273 (spheres in buffer order)
@@ -492,15 +503,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                     }
                 }
             }
+            RT_MARK("end shade");
         } else {
             // ================================ TRAVERSAL BURST ================================
             if constexpr (TRI) {
             __builtin_amdgcn_s_setprio(1);
+            RT_MARK("begin burst");
+            if (COUNT && lane == 0) cnt.sched[2]++;
             // while-while over the lanes in flight: node steps until no lane holds an internal node, then every lane
             // tests its whole leaf.  The burst ends when all queries are complete, or as soon as `shade_threshold`
             // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
             for (;;) {
+                RT_MARK("begin burstiter");
+                if (COUNT && lane == 0) cnt.sched[3]++;
                 for (;;) {
+                    RT_MARK("begin nodeloop");
+                    if (COUNT && lane == 0) cnt.sched[4]++;
                     // (cur is an internal node only while the lane traverses: every exit from kModeTrav sets cur = kNone)
                     const int nAtNode = __popcll(ballot_((int)cur >= 0));
                     if (nAtNode == 0) break;
@@ -513,6 +531,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                     }
 #endif
                     if ((int)cur >= 0) {
+                        RT_MARK("begin node");
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
 #ifdef RT_DIAG_TOP       // diagnostic build only (tools/diag_primary.py top): node steps at the first RT_DIAG_TOP / 4 x RT_DIAG_TOP + 1 nodes (breadth-first order)
@@ -546,13 +565,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         if (t0 < INF) cur = c0;
                         else if (top != stk0) cur = pop();
                         else { cur = kNone; mode = kModeShade; }
+                        RT_MARK("end node");
                     }
+                    RT_MARK("end nodeloop");
                 }
                 if (mode == kModeTrav && (int)cur < 0) {            // a leaf = kLeafBit | first << 2 | count-1
+                    RT_MARK("begin leaf");
+                    if (COUNT && (unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.sched[1]++;
                     uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
                     const uint32_t last = ti + (cur & 3u);
                     if (cur != kNone)           // (an empty child slot can never be entered by a traceable ray; never decode one)
                     for (; ti <= last; ++ti) {
+                        RT_MARK("begin tri");
                         float4 g0, g1, g2;
                         load_tri(S.tri_geo, ti, g0, g1, g2);
                         float dst, u, v;
@@ -579,19 +603,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             }
                             if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
                         }
+                        RT_MARK("end tri");
                     }
                     if (top != stk0) cur = pop();
                     else { cur = kNone; mode = kModeShade; }
+                    RT_MARK("end leaf");
                 }
+                RT_MARK("end burstiter");
                 if (ballot_(mode == kModeTrav) == 0) break;
                 if ((int)__popcll(ballot_(mode == kModeShade)) >= thr) break;
             }
+            RT_MARK("end burst");
             }       // (TRI)
         }
     }
     {
         unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
         for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
+        for (int k = 0; k < 6; ++k) v[15 + k] = cnt.sched[k];
         for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

@@ -129,6 +129,7 @@ namespace RtMi355x
         public int bvhRepads;
         public int lastSampleLanes;
         public int queuedLaunches;
+        public fixed ulong schedExecs[6];
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -255,8 +255,6 @@ def test_million_triangle_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
     assert rays == cnt["rays"] > 150_000_000
 
 
-@pytest.mark.skipif(os.environ.get("RTX_FULL_TESTS", "0") != "1", reason="~9.7e8 oracle rays (about 80 s of the box's host cores): RTX_FULL_TESTS=1 runs it; "
-                    "passed on the final round-3 build (profiles/README.md)")
 def test_4k_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
     """configs[3] exactly as bench.py --config 4 runs it: 3840x2160, 64 rays per pixel, 12 bounces — all 8,294,400 pixels of a frame and
     the ray count (~9.7e8) against the oracle (its own search tree; the literal loop is covered at 1 ray per pixel above)."""
@@ -264,6 +262,42 @@ def test_4k_frame_as_benchmarked_vs_oracle(rtx, oracle, tracer):
     assert (m.numRaysPerPixel, m.maxBounceCount) == (64, 12)
     rays, cnt = _full_frame_vs_oracle(oracle, tracer, m, "config4 4K x64 vs oracle", frame=1)
     assert rays == cnt["rays"] > 800_000_000
+
+
+def test_4k_sixty_four_frames_accumulated_vs_oracle(rtx, oracle, tracer):
+    """configs[3]'s 4096 spp are 64 frames of 64 rays: here the 64 FRAMES at 3840x2160 and 12 bounces with 1 ray per pixel — four launches'
+    worth of 16-frame groups through the saturating accumulate (Accumulate.shader:43-54), one rt_render call — against the oracle: all
+    8,294,400 pixels of resultTexture and the ray count."""
+    m = rtx.scenes.config4()
+    m.numRaysPerPixel = 1
+    b = m.build_buffers()
+    acc, last = run_gpu(tracer, b, 0, 64, kernel=-1)
+    st = tracer.stats()
+    assert acc.shape == (2160, 3840, 4) and st["numRenderedFrames"] == 64
+    want, want_last, cnt = oracle.render(*b, 0, 64, accel=True)
+    assert_bitwise(last, want_last, "4K, frame 63")
+    assert_bitwise(acc, want, "4K, 64 frames accumulated")
+    assert st["rays"] == cnt["rays"] > 500_000_000
+
+
+@pytest.mark.skipif(os.environ.get("RTX_FULL_TESTS", "0") != "1", reason="the whole 1024-spp job of configs[4] through the oracle: about five minutes of the "
+                    "box's host cores; RTX_FULL_TESTS=1 runs it (its output of this round: profiles/validate_config5_r04.txt)")
+def test_million_triangle_whole_job_vs_oracle(rtx, oracle, tracer):
+    """configs[4] as a whole job: 1,004,364 triangles, depth of field, 1920x1080, 16 frames x 64 rays accumulated (1024 spp), 8 bounces —
+    resultTexture and the ray count against the oracle (what tools/validate_headline.py does for the headline scene)."""
+    b = rtx.scenes.config5().build_buffers()
+    acc, _ = run_gpu(tracer, b, 0, 16, kernel=-1)
+    rays = tracer.stats()["rays"]
+    want, total = None, 0
+    for f in range(16):
+        cur, cnt = oracle.render_frame(*b, f, accel=True)
+        if want is None:
+            want = np.zeros_like(cur)
+        oracle.accumulate(want, cur, f)
+        total += cnt["rays"]
+    assert_bitwise(acc, want, "config5 whole job, 16 frames accumulated")
+    assert rays == total > 3_000_000_000
+    print(f"config5 whole job: {rays} rays, resultTexture bit-identical to the oracle")
 
 
 def test_headline_job_two_frames_accumulated_vs_oracle(rtx, oracle, tracer):

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Static instruction counts of k_stream's regions, from the assembly of its code object.
+
+k_stream is a persistent loop over a handful of regions (group fetch, SHADE pass with its hit / environment / camera blocks, traversal
+burst with node steps, leaf phases and triangle tests).  The counting build of the kernel counts how often a wave executes each of them
+(rt_stats.phaseExecs, rt_stats.schedExecs); this tool counts what one execution costs: it compiles the kernels' translation unit to
+assembly with -DRT_MARKERS — rt_stream.hpp then emits an assembler comment at every region boundary, nothing else changes — and counts
+the VALU / vector-memory / LDS / scalar instructions between the markers (innermost region wins; the blocks behind RT_COLD_PATH, the
+IEEE fall-backs that never run on real inputs, are left out).  executions x static counts = the launch's VALU wave-instructions without
+a profiler pass; bench.py puts that number next to the rocprofv3 figure (roofline.valu_model).
+
+    python tools/static_valu.py            -> ray-tracing-extended_amd/static_valu.json (stamped with the hash of the kernel sources)
+
+The unmarked compile is assembled as well: its total VALU count must equal the marked one's (the markers are comments in side-effect
+asm statements; if they perturbed code generation the tool says so in `marker_drift`)."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+
+CSRC = g.CSRC
+OUT = os.path.join(ROOT, "ray-tracing-extended_amd", "static_valu.json")
+REGIONS = ("loop", "fetch", "shade", "hit", "env", "camera", "burst", "burstiter", "nodeloop", "node", "leaf", "tri")
+
+
+def csrc_sha16():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hpp", ".hip", ".cpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "rt.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def assemble(extra):
+    hipcc = g.shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([hipcc, *flags, *g.STREAM_TU_FLAGS, *extra, "--offload-device-only", "-S",
+                               os.path.join(CSRC, "rt_stream_kernels.hip"), "-o", out], stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+def kind(mnemonic):
+    if mnemonic.startswith("v_"):
+        return "valu"
+    if mnemonic.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    if mnemonic.startswith("ds_"):
+        return "lds"
+    if mnemonic.startswith("s_"):
+        return "salu"
+    return "other"
+
+
+def kernels(text):
+    """mangled name -> list of assembly lines of the function body"""
+    out = {}
+    for m in re.finditer(r"^(_ZN3rtk8k_stream\w+):", text, re.M):
+        end = text.index(".Lfunc_end", m.end())
+        out[m.group(1)] = text[m.end():end].split("\n")
+    return out
+
+
+def count(lines, marked):
+    regions = {r: {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0} for r in REGIONS}
+    cold = {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0}
+    stack, in_cold, problems = ["loop"], False, []
+    for ln in lines:
+        t = ln.strip()
+        if not t:
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            in_cold = False                      # a cold block ends at the next label
+            continue
+        m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
+        if m and marked:
+            if m.group(1) == "begin":
+                stack.append(m.group(2))
+            elif len(stack) > 1 and stack[-1] == m.group(2):
+                stack.pop()
+            else:
+                problems.append(f"end {m.group(2)} while in {stack[-1]}")
+                while len(stack) > 1 and stack[-1] != m.group(2):
+                    stack.pop()
+                if len(stack) > 1:
+                    stack.pop()
+            continue
+        if t.startswith("; RTCOLD"):
+            in_cold = True
+            continue
+        if t.startswith((";", ".")):
+            continue
+        k = kind(t.split()[0])
+        (cold if in_cold else regions[stack[-1]])[k] += 1
+    return regions, cold, problems
+
+
+def main():
+    marked, plain = assemble(["-DRT_MARKERS"]), assemble([])
+    km, kp = kernels(marked), kernels(plain)
+    table = {"csrc_sha16": csrc_sha16(), "regions": list(REGIONS),
+             "note": "static instruction counts per region of k_stream (exclusive: the innermost region owns an instruction; cold = blocks behind "
+                     "RT_COLD_PATH, never executed on real inputs); template arguments <COUNT, PHILOX, H, TRI>",
+             "kernels": {}}
+    for name, lines in km.items():
+        targs = re.search(r"k_streamILb(\d)ELb(\d)ELb(\d)ELb(\d)E", name).groups()
+        if targs[0] == "1":
+            continue                             # the counting instantiations carry the counters' own instructions
+        regions, cold, problems = count(lines, True)
+        pregions, pcold, _ = count(kp[name], False)
+        total_marked = sum(r["valu"] for r in regions.values()) + cold["valu"]
+        total_plain = sum(r["valu"] for r in pregions.values()) + pcold["valu"]
+        key = "k_stream<false,%s,%s,%s>" % tuple("true" if a == "1" else "false" for a in targs[1:])
+        table["kernels"][key] = {"valu": {r: regions[r]["valu"] for r in REGIONS}, "vmem": {r: regions[r]["vmem"] for r in REGIONS},
+                                 "lds": {r: regions[r]["lds"] for r in REGIONS}, "salu": {r: regions[r]["salu"] for r in REGIONS},
+                                 "cold_valu": cold["valu"], "total_valu": total_marked, "total_valu_without_markers": total_plain,
+                                 "marker_drift": total_marked - total_plain, "marker_problems": problems}
+    json.dump(table, open(OUT, "w"), indent=1)
+    for key, e in table["kernels"].items():
+        print(key, "VALU", e["valu"], "| cold", e["cold_valu"], "| total", e["total_valu"], "(unmarked:", e["total_valu_without_markers"], ")", e["marker_problems"][:2])
+
+
+if __name__ == "__main__":
+    main()
