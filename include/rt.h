@@ -168,6 +168,12 @@ typedef struct rt_stats {
                                         /* 1 leaf phases, 2 traversal bursts, 3 outer iterations of the bursts, 4 node-loop iterations,   */
                                         /* 5 group fetches (with phaseExecs and the regions' static instruction counts: the launch's     */
                                         /* VALU instruction count without a profiler, bench.py roofline.valu_model)                      */
+    uint32_t primaryLists[4];           /* camera rays' candidate lists of the last build (k_stream, static camera): pixels whose camera rays  */
+                                        /* start from <= 4 leaves bounded by a common triangle / from an unbounded list / certainly miss         */
+                                        /* everything / start at the root (no list)                                                              */
+    int32_t  primaryListBuilds;         /* times the lists were built since rt_create                                                            */
+    int32_t  _reserved;
+    double   lastPrimaryListsMs;        /* HIP-event time of the last build of the lists                                                         */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -250,6 +256,10 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     this percentage of its value right after the last build (default 200; 0 = never)
  *   "compact_nodes"   k_trace / k_stream: 1 = traverse the f16 form of the BVH nodes (5 loads per node visit, default), 0 = the
  *                     f32 form (7 loads)
+ *   "primary_lists"   k_stream, depth of field off: 1 (default) = once the camera stands still (a launch of several frames, or the same
+ *                     parameters as the previous launch), every pixel's camera rays start from the <= 4 BVH leaves that can hold their closest
+ *                     hit — found once per camera / scene by tracing the corners of the pixel's jitter footprint (csrc/rt_primary.hpp) —
+ *                     instead of from the root; 0 = always from the root.  The image does not depend on it.
  *   "queue_depth", "queue_linger_us"   rt_submit_frame: most frames the queue's worker puts into one launch (1..256, default 64); how long
  *                     it waits for more frames after the first one of an idle queue arrived (default 200 us: a burst becomes one launch)
  *   "blocks_per_cu"   cap on resident workgroups per CU (0 = occupancy query)                                     */

@@ -43,6 +43,7 @@ STATS = np.dtype([
     ("lastKernel", "<i4"), ("lastFramesInterleaved", "<i4"),
     ("lastBvhBuildMs", "<f8"), ("refitAreaRatio", "<f4"), ("bvhInternalArea", "<f4"), ("bvhBuiltOnDevice", "<i4"), ("bvhBuilds", "<i4"),
     ("bvhRebuilds", "<i4"), ("bvhRepads", "<i4"), ("lastSampleLanes", "<i4"), ("queuedLaunches", "<i4"), ("schedExecs", "<u8", 6),
+    ("primaryLists", "<u4", 4), ("primaryListBuilds", "<i4"), ("_reserved", "<i4"), ("lastPrimaryListsMs", "<f8"),
 ])
 MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])
 MULTI_INFO = np.dtype([("numContexts", "<i4"), ("bvhBuilds", "<i4"), ("lastSetupMs", "<f8"), ("lastGatherMs", "<f8"),

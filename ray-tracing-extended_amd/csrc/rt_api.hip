@@ -24,6 +24,7 @@
 namespace rtk { const void* stream_kernel(bool counting, bool philox, bool compact, bool triangles); }   // rt_stream_kernels.hip
 #include "rt_geom.hpp"
 #include "rt_bvh_gpu.hpp"
+#include "rt_primary.hpp"
 
 namespace {
 
@@ -142,6 +143,11 @@ struct rt_ctx {
                                     // tables = 31,744 B per workgroup: five workgroups per CU (32,768 B already makes it four: measured -11 %)
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     DevBuf<uint32_t> d_gstack;
+    // camera rays' candidate lists (rt_primary.hpp): valid for one (params, rows, scene) combination
+    DevBuf<uint4> d_primary; DevBuf<unsigned int> d_primary_counts;
+    std::string primary_key, last_launch_key;      // what the lists were built for; what the previous launch rendered
+    unsigned long long scene_version = 0;           // bumped whenever the tree or its boxes change (build, refit, re-padding)
+    int opt_primary_lists = 1;                      // 1: camera rays of a static camera start from their pixel's candidate leaves (k_stream); 0: always from the root
     DevBuf<float> d_park;              // k_stream, Philox mode: parked sub-stream sums
     rt_stats stats{};
 
@@ -262,7 +268,7 @@ int device_build(rt_ctx* c, uint32_t nt, float origin_magnitude)
     RT_HIP(c, rtgb::internal_area(c->stream, reinterpret_cast<const rtbvh::Node4*>(c->d_nodes.p), (uint32_t)c->n_nodes, c->bvh_ws, c->area_at_build));
     float ms = 0.f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
-    c->stats.lastBvhBuildMs = ms; c->stats.bvhBuiltOnDevice = 1; c->stats.bvhBuilds++;
+    c->stats.lastBvhBuildMs = ms; c->stats.bvhBuiltOnDevice = 1; c->stats.bvhBuilds++; c->scene_version++;
     return 0;
 }
 
@@ -370,7 +376,7 @@ int build_scene(rt_ctx* c)
     c->stats.numSpheres = (int)ns; c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->n_nodes; c->stats.bvhMaxStack = c->bvh.maxStack; c->stats.bvhInternalArea = c->area_at_build;
     c->n_spheres = ns; c->n_tris = nt; c->n_chunks = nm; c->sphere_mag = sphere_magnitude(c);
-    c->scene_dirty = false; c->tile_order_valid = false;
+    c->scene_dirty = false; c->tile_order_valid = false; c->scene_version++;
     return 0;
 }
 
@@ -391,7 +397,7 @@ int repad_boxes(rt_ctx* c, float G)
         { int r = compact_nodes(c); if (r) return r; }
     }
     c->bvh.magnitude = G;
-    c->stats.bvhRepads++;
+    c->stats.bvhRepads++; c->scene_version++;
     return 0;
 }
 
@@ -470,7 +476,7 @@ int run_geometry_kernels(rt_ctx* c, bool have_bvh)
     RT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
-    c->stats.lastGeometryMs = ms;
+    c->stats.lastGeometryMs = ms; c->scene_version++;
     if (check_area) {
         const float area = c->area_after_refit;
         c->stats.refitAreaRatio = area / c->area_at_build;
@@ -538,7 +544,7 @@ int build_scene_local(rt_ctx* c)
     c->stats.numTriangles = (int)nt; c->stats.numMeshChunks = (int)nm;
     c->stats.numBvhNodes = (int)c->n_nodes; c->stats.bvhMaxStack = c->bvh.maxStack; c->stats.bvhInternalArea = c->area_at_build;
     c->n_spheres = c->h_spheres.size(); c->n_tris = nt; c->n_chunks = nm; c->sphere_mag = sphere_magnitude(c);
-    c->scene_dirty = false; c->xf_dirty = false; c->tile_order_valid = false;
+    c->scene_dirty = false; c->xf_dirty = false; c->tile_order_valid = false; c->scene_version++;
     return 0;
 }
 
@@ -572,7 +578,7 @@ int clone_scene(rt_ctx* dst, rt_ctx* src)
     dst->stats.numSpheres = src->stats.numSpheres; dst->stats.numTriangles = src->stats.numTriangles; dst->stats.numMeshChunks = src->stats.numMeshChunks;
     dst->stats.numBvhNodes = src->stats.numBvhNodes; dst->stats.bvhMaxStack = src->stats.bvhMaxStack; dst->stats.bvhInternalArea = src->stats.bvhInternalArea;
     dst->stats.bvhBuiltOnDevice = src->stats.bvhBuiltOnDevice; dst->stats.lastBvhBuildMs = 0.0;
-    dst->scene_dirty = false; dst->tile_order_valid = false; dst->auto_choice = -1;
+    dst->scene_dirty = false; dst->tile_order_valid = false; dst->auto_choice = -1; dst->scene_version++;
     return 0;
 }
 
@@ -747,6 +753,40 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         }
         F.tile_order = c->tile_order_valid ? c->d_tile_order.p : nullptr;
         F.tile_cost = record_costs ? c->d_tile_cost.p : nullptr;
+    }
+    // ---- camera rays' candidate lists: for a camera that stands still (this launch renders what the previous one rendered, or traces
+    // several frames itself) every pixel's camera rays start from <= 4 leaves found once (rt_primary.hpp).  A camera that moves every
+    // frame never pays for them.
+    {
+        std::string key((const char*)&c->params, sizeof c->params);
+        const unsigned long long geo[6] = { c->scene_version, (unsigned long long)c->target_row0, (unsigned long long)c->target_rows,
+                                            (unsigned long long)c->target_row_stride, (unsigned long long)c->target_w, (unsigned long long)c->target_h };
+        key.append((const char*)geo, sizeof geo);
+        const bool eligible = stream && c->opt_primary_lists && c->n_nodes > 0 && F.fixed_origin && c->target_pixels > 0;
+        if (eligible && (n_frames >= 2 || key == c->last_launch_key)) {
+            if (key != c->primary_key) {
+                RT_HIP(c, c->d_primary.ensure(c->target_pixels)); RT_HIP(c, c->d_primary_counts.ensure(4));
+                RT_HIP(c, hipMemsetAsync(c->d_primary_counts.p, 0, 4 * sizeof(unsigned int), c->stream));
+                rtp::PrimaryArgs PA{};
+                PA.p = c->params; PA.row0 = c->target_row0; PA.nrows = c->target_rows; PA.row_stride = c->target_row_stride;
+                PA.lists = c->d_primary.p; PA.counts = c->d_primary_counts.p;
+                const int tiles = ((c->target_w + 7) / 8) * ((c->target_rows + 7) / 8);
+                RT_HIP(c, hipEventRecord(c->evg0, c->stream));
+                hipLaunchKernelGGL(rtp::k_primary_lists, dim3(tiles), dim3(64), 0, c->stream, S, PA);
+                RT_HIP(c, hipGetLastError());
+                RT_HIP(c, hipEventRecord(c->evg1, c->stream));
+                unsigned int h[4];
+                RT_HIP(c, hipMemcpyAsync(h, c->d_primary_counts.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                RT_HIP(c, hipStreamSynchronize(c->stream));
+                float ms = 0.f;
+                RT_HIP(c, hipEventElapsedTime(&ms, c->evg0, c->evg1));
+                for (int k = 0; k < 4; ++k) c->stats.primaryLists[k] = h[k];
+                c->stats.lastPrimaryListsMs = ms; c->stats.primaryListBuilds++;
+                c->primary_key = key;
+            }
+            F.primary = c->d_primary.p;
+        }
+        c->last_launch_key = key;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
@@ -1007,6 +1047,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
+    c->d_primary.release(); c->d_primary_counts.release();
     c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_park.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -1165,6 +1206,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "rebuild_percent")) { if (value < 0 || value > 100000) return fail(c, -2, "rebuild_percent must be in [0,100000] (0 = never rebuild)"); c->opt_rebuild_percent = value; }
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }
     else if (!std::strcmp(name, "full_sort")) c->opt_full_sort = value ? 1 : 0;
+    else if (!std::strcmp(name, "primary_lists")) { if (value != 0 && value != 1) return fail(c, -2, "primary_lists must be 0 or 1"); c->opt_primary_lists = value; }
     else if (!std::strcmp(name, "queue_depth")) { if (value < 1 || value > 256) return fail(c, -2, "queue_depth must be in [1,256]"); c->opt_queue_depth = value; }
     else if (!std::strcmp(name, "queue_linger_us")) { if (value < 0 || value > 1000000) return fail(c, -2, "queue_linger_us must be in [0,1000000]"); c->opt_queue_linger_us = value; }
     else if (!std::strcmp(name, "blocks_per_cu")) { if (value < 0) return fail(c, -2, "blocks_per_cu must be >= 0"); c->opt_blocks_per_cu = value; }

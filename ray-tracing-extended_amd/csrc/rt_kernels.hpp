@@ -61,6 +61,8 @@ struct FrameArgs {
     float4* out_frame;          // [nrows*W] currentFrame
     float4* accum;              // [nrows*W] resultTexture
     float* park;                // k_stream, Philox mode: per wave [items of a group][3][64] sub-stream sums waiting for the estimator's tree; else null
+    const uint4* primary;       // k_stream: per local pixel, up to four leaf references a camera ray of that pixel starts with instead of the root
+                                // (rt_primary.hpp: .x = 0xFFFFFFFE no list, kNone-terminated, all kNone = certain miss); null = every ray starts at the root
     unsigned int* tile_counter;
     unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5], sched[6]
 };

@@ -498,6 +498,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             if (S.nn > 0 && traceable) {
                                 slab = make_slab<H>(o, d);                              // RayBoundingBox :179
                                 cur = 0; top = stk0; mode = kModeTrav;
+                                // A camera ray of a pixel with a candidate list (rt_primary.hpp: every triangle a ray through the pixel's footprint can hit
+                                // first lies in these <= 4 leaves) starts with the leaves on its stack instead of the root: no node step at all.
+                                if (F.primary != nullptr && need_ray) {
+                                    const uint4 L = F.primary[(size_t)(pxy >> 16) * W + (pxy & 0xFFFFu)];
+                                    if (L.x != 0xFFFFFFFEu) {
+                                        cur = L.x;
+                                        slot(top) = L.w; top = (L.w != kNone) ? top + 256u : top;      // (branch-free, like the node step's pushes;
+                                        slot(top) = L.z; top = (L.z != kNone) ? top + 256u : top;      //  the stack has three entries of slack)
+                                        slot(top) = L.y; top = (L.y != kNone) ? top + 256u : top;
+                                        if (L.x == kNone) mode = kModeShade;                            // nothing in the footprint's frustum: a certain miss
+                                    }
+                                }
                             }
                         }
                     }

@@ -130,6 +130,10 @@ namespace RtMi355x
         public int lastSampleLanes;
         public int queuedLaunches;
         public fixed ulong schedExecs[6];
+        public fixed uint primaryLists[4];
+        public int primaryListBuilds;
+        public int _reserved;
+        public double lastPrimaryListsMs;
     }
 
     [StructLayout(LayoutKind.Sequential)]

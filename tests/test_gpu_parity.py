@@ -524,3 +524,44 @@ def test_queued_submission_reports_the_error_of_a_queued_launch(rtx, tracer):
     tracer.submit_frame(0)
     tracer.wait()
     assert tracer.stats()["numRenderedFrames"] == 1
+
+
+@pytest.mark.parametrize("size,diverge", [((96, 64), None), ((31, 23), None), ((200, 120), 0.0), ((64, 48), 40.0)])
+@pytest.mark.parametrize("philox", [0, 1])
+def test_camera_ray_candidate_lists_do_not_change_the_image(rtx, oracle, tracer, size, diverge, philox):
+    """Option primary_lists (csrc/rt_primary.hpp): with the camera standing still, every pixel's camera rays start from the <= 4 BVH leaves
+    that can hold their closest hit instead of from the root.  Image, last frame and ray count with the lists == without == the oracle:
+    pixels much larger than the triangles (31x23), a footprint of zero size (DivergeStrength 0), one of many pixels (40), both RNG modes;
+    the lists are really in use (statistics), and a camera move or a scene change builds them again."""
+    m = rtx.scenes.mesh_test_scene(*size)
+    if diverge is not None:
+        m.divergeStrength = diverge
+    params, spheres, tris, infos = m.build_buffers()
+    params = params.copy(); params["rngMode"] = philox
+    b = (params, spheres, tris, infos)
+    want, want_last, cnt = oracle.render(*b, 1, 3)
+    tracer.set_option("primary_lists", 0)
+    try:
+        off, off_last = run_gpu(tracer, b, 1, 3, kernel=1)
+        builds0 = tracer.stats()["primaryListBuilds"]
+    finally:
+        tracer.set_option("primary_lists", 1)
+    on, on_last = run_gpu(tracer, b, 1, 3, kernel=1)
+    st = tracer.stats()
+    assert st["primaryListBuilds"] == builds0 + 1 and sum(st["primaryLists"]) == size[0] * size[1]
+    assert_bitwise(off, want, "without candidate lists")
+    assert_bitwise(on, want, "with candidate lists: accum")
+    assert_bitwise(on_last, want_last, "with candidate lists: last frame")
+    assert st["rays"] == cnt["rays"]
+    if diverge is None and size == (96, 64):
+        assert st["primaryLists"][0] + st["primaryLists"][1] + st["primaryLists"][2] > 0.5 * size[0] * size[1]     # most pixels have a list
+        tracer.render(4, 2)                                  # same camera, same scene: the lists stay
+        assert tracer.stats()["primaryListBuilds"] == builds0 + 1
+        p2 = params.copy(); p2["worldSpaceCameraPos"] = params["worldSpaceCameraPos"] + np.float32([0.25, 0.0, 0.0])
+        mm = p2["camLocalToWorld"].copy(); mm[3] += np.float32(0.25); p2["camLocalToWorld"] = mm
+        tracer.set_params(p2); tracer.reset_accum(); tracer.render(1, 3)
+        assert tracer.stats()["primaryListBuilds"] == builds0 + 2
+        moved, _, _ = oracle.render(p2, spheres, tris, infos, 1, 3)
+        assert_bitwise(tracer.read_accum(), moved, "candidate lists after a camera move")
+        tracer.render_frame(4); tracer.set_params(params); tracer.reset_accum(); tracer.render_frame(0)     # single frames of a moving camera: no build
+        assert tracer.stats()["primaryListBuilds"] == builds0 + 2
