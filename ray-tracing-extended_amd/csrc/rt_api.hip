@@ -145,7 +145,7 @@ struct rt_ctx {
     DevBuf<uint32_t> d_gstack;
     // camera rays' candidate lists (rt_primary.hpp): valid for one (params, rows, scene) combination
     DevBuf<uint4> d_primary; DevBuf<unsigned int> d_primary_counts;
-    std::string primary_key, last_launch_key;      // what the lists were built for; what the previous launch rendered
+    std::string primary_key;                        // what the lists were built for (parameters, rows, scene version)
     unsigned long long scene_version = 0;           // bumped whenever the tree or its boxes change (build, refit, re-padding)
     int opt_primary_lists = 1;                      // 1: camera rays of a static camera start from their pixel's candidate leaves (k_stream); 0: always from the root
     DevBuf<float> d_park;              // k_stream, Philox mode: parked sub-stream sums
@@ -754,16 +754,14 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         F.tile_order = c->tile_order_valid ? c->d_tile_order.p : nullptr;
         F.tile_cost = record_costs ? c->d_tile_cost.p : nullptr;
     }
-    // ---- camera rays' candidate lists: for a camera that stands still (this launch renders what the previous one rendered, or traces
-    // several frames itself) every pixel's camera rays start from <= 4 leaves found once (rt_primary.hpp).  A camera that moves every
-    // frame never pays for them.
+    // ---- camera rays' candidate lists: every pixel's camera rays start from <= 4 leaves found once per camera / scene (rt_primary.hpp)
     {
         std::string key((const char*)&c->params, sizeof c->params);
         const unsigned long long geo[6] = { c->scene_version, (unsigned long long)c->target_row0, (unsigned long long)c->target_rows,
                                             (unsigned long long)c->target_row_stride, (unsigned long long)c->target_w, (unsigned long long)c->target_h };
         key.append((const char*)geo, sizeof geo);
-        const bool eligible = stream && c->opt_primary_lists && c->n_nodes > 0 && F.fixed_origin && c->target_pixels > 0;
-        if (eligible && (n_frames >= 2 || key == c->last_launch_key)) {
+        const bool eligible = stream && c->opt_primary_lists && c->n_nodes > 0 && F.fixed_origin && c->target_pixels > 0 && c->bvh.maxStack <= 160;
+        if (eligible) {                 // (the build takes well under a millisecond at 1080p: a camera that moves every frame pays it every frame and still gains)
             if (key != c->primary_key) {
                 RT_HIP(c, c->d_primary.ensure(c->target_pixels)); RT_HIP(c, c->d_primary_counts.ensure(4));
                 RT_HIP(c, hipMemsetAsync(c->d_primary_counts.p, 0, 4 * sizeof(unsigned int), c->stream));
@@ -771,8 +769,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
                 PA.p = c->params; PA.row0 = c->target_row0; PA.nrows = c->target_rows; PA.row_stride = c->target_row_stride;
                 PA.lists = c->d_primary.p; PA.counts = c->d_primary_counts.p;
                 const int tiles = ((c->target_w + 7) / 8) * ((c->target_rows + 7) / 8);
+                PA.stack_cap = std::max(1, c->bvh.maxStack);                       // (the whole worst case in LDS: at most 160 entries x 64 lanes x 4 B = 40 KB per wave)
+                const size_t plds = (size_t)PA.stack_cap * 64 * sizeof(uint32_t);
                 RT_HIP(c, hipEventRecord(c->evg0, c->stream));
-                hipLaunchKernelGGL(rtp::k_primary_lists, dim3(tiles), dim3(64), 0, c->stream, S, PA);
+                hipLaunchKernelGGL(rtp::k_primary_lists, dim3(tiles), dim3(64), plds, c->stream, S, PA);
                 RT_HIP(c, hipGetLastError());
                 RT_HIP(c, hipEventRecord(c->evg1, c->stream));
                 unsigned int h[4];
@@ -786,7 +786,6 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
             }
             F.primary = c->d_primary.p;
         }
-        c->last_launch_key = key;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));

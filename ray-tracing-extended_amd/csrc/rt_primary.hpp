@@ -6,12 +6,14 @@
 // list for every one of them (RayTracing.shader:276-294); the BVH replaced that by ~9 node steps per ray; for most pixels a handful
 // of triangles is all that any ray through the footprint can possibly hit first.  k_primary_lists finds them once per camera / scene:
 //
-//   1. the four corner rays of the footprint's bounding square (widened: see below) are traced to their closest front-facing hit;
+//   1. the four corner rays of the footprint's bounding square (widened: see below) are traced to their closest hit with the tracer's own
+//      traversal (float, f16 nodes, LDS stack): these hits only NOMINATE triangles, nothing is concluded from them;
 //   2. a triangle T that ALL FOUR corner rays hit with barycentrics >= kBaryMargin and determinant >= kDetMargin is hit by every ray
 //      of the footprint (a central projection maps the square's convex hull onto a convex region of T's plane inside T), no farther
-//      than the farthest corner hit, and robustly so in the kernels' float arithmetic (the margins dwarf its rounding errors): the
-//      closest hit of every camera ray of the pixel therefore lies within t_max = that distance (+ margin).  Without such a T,
-//      t_max = infinity;
+//      than the farthest corner hit, and robustly so in the kernels' float arithmetic (the margins dwarf its rounding errors; with the
+//      reference's chunk cull in force, RT_INTERSECT_FLAT_CHUNKS, T's chunk box must pass RayBoundingBox with the same kind of margin
+//      for all four corners): the closest hit of every camera ray of the pixel therefore lies within t_max = that distance (+ margin).
+//      Without such a T, t_max = infinity;
 //   3. every leaf whose (padded) box meets the footprint's frustum — four planes through the camera position — within t_max is a
 //      candidate; a triangle in any other leaf cannot be the closest hit of a ray of this pixel: a hit the kernels' arithmetic accepts
 //      lies inside its leaf's padded box (that is what the padding is for, bvh.cpp pad_box), and the ray lies inside the frustum.
@@ -32,14 +34,6 @@ namespace rtp {
 constexpr uint32_t kNoList = 0xFFFFFFFEu;       // lists[pixel].x: no list, start at the root (rtk::kNone in .x = certain miss: an empty list)
 constexpr int kMaxList = 4;
 constexpr double kWiden = 1.05, kBaryMargin = 0.01, kDetMargin = 1.5e-6, kTmaxMargin = 1.0001;
-constexpr int kStack = 128;
-
-struct PrimaryArgs {
-    rt_params p;
-    int row0, nrows, row_stride;        // as FrameArgs: local row ly -> global row row0 + (ly / 8) * row_stride + ly % 8
-    uint4* lists;                       // [nrows * width]
-    unsigned int* counts;               // [4] pixels with a list bounded by a common triangle, with an unbounded list, certainly missing everything, without a list
-};
 
 struct D3 { double x, y, z; };
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
@@ -47,6 +41,36 @@ __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return { a.x + b.x, a.y + 
 __device__ __forceinline__ D3 operator*(D3 a, double s) { return { a.x * s, a.y * s, a.z * s }; }
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ D3 cross(D3 a, D3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+
+// The reference's RayBoundingBox (:177-187) for the chunk of a nominated triangle, in double and with margins: true only when the float
+// evaluation passes for certain — every near plane of one axis lies before every far plane of the OTHER axes by a margin (the two
+// planes of one axis are compared exactly in float as well: min and max of the same two numbers).
+__device__ __forceinline__ bool chunk_box_passes_for_certain(const float4 bmn, const float4 bmx, D3 o, D3 d)
+{
+    const double lo[3] = { bmn.x, bmn.y, bmn.z }, hi[3] = { bmx.x, bmx.y, bmx.z }, oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    double t1[3], t2[3];
+    for (int a = 0; a < 3; ++a) {
+        if (!(fabs(dd[a]) > 1e-12)) {                                   // (nearly) parallel to the slab: inside it for certain, or no conclusion
+            if (!(oo[a] > lo[a] + 1e-6 * (1.0 + fabs(lo[a])) && oo[a] < hi[a] - 1e-6 * (1.0 + fabs(hi[a])))) return false;
+            t1[a] = -1e300; t2[a] = 1e300;
+            continue;
+        }
+        const double ta = (lo[a] - oo[a]) / dd[a], tb = (hi[a] - oo[a]) / dd[a];
+        t1[a] = fmin(ta, tb); t2[a] = fmax(ta, tb);
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            if (a != b && !(t1[a] + 1e-5 * (1.0 + fabs(t1[a])) <= t2[b])) return false;
+    return true;
+}
+
+struct PrimaryArgs {
+    rt_params p;
+    int row0, nrows, row_stride;        // as FrameArgs: local row ly -> global row row0 + (ly / 8) * row_stride + ly % 8
+    uint4* lists;                       // [nrows * width]
+    int stack_cap;                      // LDS stack entries per lane (the BVH's worst case)
+    unsigned int* counts;               // [4] pixels with a list bounded by a common triangle, with an unbounded list, certainly missing everything, without a list
+};
 
 // RayTriangle (:150-174) in double on the tracer's own operands (A, eAB, eAC, cross(eAB, eAC) of the BVH-order record); d = unit direction
 __device__ __forceinline__ bool tri_hit(const float4* __restrict__ tri_geo, uint32_t ti, D3 o, D3 d, double& dst, double& u, double& v, double& det)
@@ -61,43 +85,6 @@ __device__ __forceinline__ bool tri_hit(const float4* __restrict__ tri_geo, uint
     return dst >= 0.0 && u >= 0.0 && v >= 0.0 && 1.0 - u - v >= 0.0;
 }
 
-// slab test of child k of an f32 node against the ray (o, 1/d) up to tmax
-__device__ __forceinline__ bool box_hit(const rtbvh::Node4& N, int k, D3 o, D3 inv, double tmax)
-{
-    double t0 = (N.minx[k] - o.x) * inv.x, t1 = (N.maxx[k] - o.x) * inv.x;
-    double a = fmin(t0, t1), b = fmax(t0, t1);
-    t0 = (N.miny[k] - o.y) * inv.y; t1 = (N.maxy[k] - o.y) * inv.y; a = fmax(a, fmin(t0, t1)); b = fmin(b, fmax(t0, t1));
-    t0 = (N.minz[k] - o.z) * inv.z; t1 = (N.maxz[k] - o.z) * inv.z; a = fmax(a, fmin(t0, t1)); b = fmin(b, fmax(t0, t1));
-    return fmax(a, 0.0) <= fmin(b, tmax) * (1.0 + 1e-9) + 1e-12;          // (NaN from 0 * inf compares false on either side: fmin / fmax drop it)
-}
-
-// closest front-facing hit of the ray (o, unit d); -1 = none.  Plain stack traversal of the f32 nodes, children pruned by the best hit.
-__device__ inline int closest(const rtk::DeviceScene& S, D3 o, D3 d, uint32_t* st, double& tbest, bool& overflow)
-{
-    const rtbvh::Node4* nodes = reinterpret_cast<const rtbvh::Node4*>(S.nodes);
-    const D3 inv{ 1.0 / d.x, 1.0 / d.y, 1.0 / d.z };
-    int best = -1; tbest = 1e300;
-    int sp = 0; st[sp++] = 0u;
-    while (sp > 0) {
-        const uint32_t c = st[--sp];
-        if (c & rtbvh::kLeafBit) {
-            const uint32_t first = (c & 0x7FFFFFFFu) >> 2, cnt = (c & 3u) + 1u;
-            for (uint32_t j = 0; j < cnt; ++j) {
-                double t, u, v, det;
-                if (tri_hit(S.tri_geo, first + j, o, d, t, u, v, det) && det >= 1e-6 && t < tbest) { tbest = t; best = (int)(first + j); }
-            }
-            continue;
-        }
-        const rtbvh::Node4& N = nodes[c];
-        for (int k = 0; k < 4; ++k) {
-            if (N.child[k] == rtbvh::kEmpty || !box_hit(N, k, o, inv, tbest)) continue;
-            if (sp >= kStack) { overflow = true; return -1; }
-            st[sp++] = N.child[k];
-        }
-    }
-    return best;
-}
-
 __global__ __launch_bounds__(64) void k_primary_lists(rtk::DeviceScene S, PrimaryArgs A)
 {
     // one lane per pixel, 8 x 8 pixels per wave (the corner rays of neighbouring pixels visit the same nodes)
@@ -110,7 +97,11 @@ __global__ __launch_bounds__(64) void k_primary_lists(rtk::DeviceScene S, Primar
     const float* M = p.camLocalToWorld;
     uint4 out = make_uint4(kNoList, rtk::kNone, rtk::kNone, rtk::kNone);
     int kind = 3;
-    uint32_t st[kStack];
+    // the traversal stack of this lane: column `lane` of stack[entry][lane] in LDS (A.stack_cap entries), as in the tracer
+    extern __shared__ uint32_t lds_stack[];
+    rtk::TravStack stk; stk.lds = lds_stack + threadIdx.x; stk.cap = A.stack_cap; stk.glb = nullptr; stk.stride = 0;
+    rtk::Counters cnt = {};
+    rtk::DeviceScene T = S; T.ns = 0;                                    // (spheres are tested for every ray anyway: the lists are about triangles)
     do {
         // the focus point exactly as the kernels compute it (frag :364-366 in float: rt_stream.hpp camera block)
         const float Wf = (float)(uint32_t)p.width;
@@ -127,51 +118,68 @@ __global__ __launch_bounds__(64) void k_primary_lists(rtk::DeviceScene S, Primar
         const double bl = sqrt(fmin(dot(right, right), dot(up, up)));
         if (!(bl > 1e-3) || !(coord < 1e30) || !(rho < 1e30)) break;                    // degenerate camera basis or non-finite input: no list
         const double r = rho * kWiden + 16.0 * 1.1920929e-7 * coord / bl;
-        D3 dir[4]; double len[4];
+        D3 dir[4], unit[4];                     // corner directions, as they are and at unit length
         bool ok = true;
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             const D3 tgt = fp + right * ((c & 1) ? r : -r) + up * ((c & 2) ? r : -r);
             dir[c] = tgt - pos;
-            len[c] = sqrt(dot(dir[c], dir[c]));
-            if (!(len[c] > 1e-30) || !(len[c] < 1e30)) ok = false;
+            const double len = sqrt(dot(dir[c], dir[c]));
+            if (!(len > 1e-30) || !(len < 1e30)) ok = false;
+            unit[c] = dir[c] * (1.0 / len);
         }
         if (!ok) break;
         const D3 centre = fp - pos;
-        // ---- 1. the corner rays' closest hits
-        int hit[4]; double thit[4]; bool overflow = false;
-        for (int c = 0; c < 4; ++c) hit[c] = closest(S, pos, dir[c] * (1.0 / len[c]), st, thit[c], overflow);
-        if (overflow) break;
+        // ---- 1. the corner rays' closest hits nominate triangles (the tracer's own float traversal; no chunk cull)
+        int hit[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const rtm::v3 of = rtm::mk(p.worldSpaceCameraPos[0], p.worldSpaceCameraPos[1], p.worldSpaceCameraPos[2]);
+            const rtm::v3 df = rtm::normalize(rtm::mk((float)dir[c].x, (float)dir[c].y, (float)dir[c].z));
+            const rtk::Hit h = rtk::closest_hit<false, true>(T, RT_INTERSECT_BRUTE, false, of, df, stk, cnt);
+            hit[c] = (h.id != rtk::kNone && (h.id & rtk::kTriBit)) ? (int)(h.id & ~rtk::kTriBit) : -1;
+        }
         // ---- 2. a triangle every corner ray hits well inside: the one whose farthest corner hit is nearest
         double tmax = 1e300;
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (hit[c] < 0) continue;
             bool seen = false;
-            for (int e = 0; e < c; ++e) seen = seen || hit[e] == hit[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) seen = seen || (e < c && hit[e] == hit[c]);
             if (seen) continue;
             double far = 0.0; bool all = true;
-            for (int q = 0; q < 4 && all; ++q) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!all) continue;
                 double t, u, v, det;
-                all = tri_hit(S.tri_geo, (uint32_t)hit[c], pos, dir[q] * (1.0 / len[q]), t, u, v, det)
+                const D3 dq = unit[q];
+                all = tri_hit(S.tri_geo, (uint32_t)hit[c], pos, dq, t, u, v, det)
                       && det >= kDetMargin && u >= kBaryMargin && v >= kBaryMargin && 1.0 - u - v >= kBaryMargin && t > 0.0;
+                if (all && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
+                    const uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)hit[c] * 3].w);
+                    all = chunk_box_passes_for_certain(S.chunk_box[(size_t)chunk * 2], S.chunk_box[(size_t)chunk * 2 + 1], pos, dq);
+                }
                 far = fmax(far, t);
             }
             if (all) tmax = fmin(tmax, far * kTmaxMargin);
         }
         // ---- 3. the leaves whose boxes meet the frustum within tmax
         // side planes through pos, normals pointing out (corners in the order (-,-) (+,-) (+,+) (-,+))
-        const int ord[4] = { 0, 1, 3, 2 };
         D3 nrm[4]; double nslack[4];
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            D3 n = cross(dir[ord[q]], dir[ord[(q + 1) & 3]]);
+            const int ca = q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 3 : 2, cb = q == 0 ? 1 : q == 1 ? 3 : q == 2 ? 2 : 0;
+            D3 n = cross(dir[ca], dir[cb]);
             if (dot(n, centre) > 0.0) n = n * -1.0;
             nrm[q] = n;
             nslack[q] = 1e-12 * (fabs(n.x) + fabs(n.y) + fabs(n.z)) * (coord + 1.0);     // double rounding of the plane test, generously
         }
         const rtbvh::Node4* nodes = reinterpret_cast<const rtbvh::Node4*>(S.nodes);
-        uint32_t found[kMaxList]; int nf = 0; bool too_many = false;
-        int sp = 0; st[sp++] = 0u;
+        uint32_t f0 = rtk::kNone, f1 = rtk::kNone, f2 = rtk::kNone, f3 = rtk::kNone; int nf = 0; bool too_many = false;
+        int sp = 0; stk.push(sp, 0u);
         while (sp > 0 && !too_many) {
-            const uint32_t c = st[--sp];
+            const uint32_t c = stk.pop(sp);
             const rtbvh::Node4& N = nodes[c];
             for (int k = 0; k < 4; ++k) {
                 if (N.child[k] == rtbvh::kEmpty) continue;
@@ -181,30 +189,39 @@ __global__ __launch_bounds__(64) void k_primary_lists(rtk::DeviceScene S, Primar
                     continue;                                            // (+inf, -inf): an empty slot's box
                 }
                 bool outside = false;
-                for (int q = 0; q < 4 && !outside; ++q) {               // the box corner deepest inside the plane's inner side is still outside
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                            // the box corner deepest inside the plane's inner side is still outside
                     const D3 pc{ nrm[q].x > 0.0 ? bx0 : bx1, nrm[q].y > 0.0 ? by0 : by1, nrm[q].z > 0.0 ? bz0 : bz1 };
-                    outside = dot(nrm[q], pc - pos) > nslack[q];
+                    outside = outside || dot(nrm[q], pc - pos) > nslack[q];
                 }
                 if (!outside && tmax < 1e299) {                          // nearest point of the box to the camera farther than tmax
                     const double dx = fmax(fmax(bx0 - pos.x, 0.0), pos.x - bx1), dy = fmax(fmax(by0 - pos.y, 0.0), pos.y - by1), dz = fmax(fmax(bz0 - pos.z, 0.0), pos.z - bz1);
-                    outside = sqrt(dx * dx + dy * dy + dz * dz) > tmax * (1.0 + 1e-9);
+                    outside = dx * dx + dy * dy + dz * dz > tmax * tmax * (1.0 + 1e-8);
                 }
                 if (outside) continue;
                 if (N.child[k] & rtbvh::kLeafBit) {
                     if (nf >= kMaxList) { too_many = true; break; }
-                    found[nf++] = N.child[k];
+                    const uint32_t leaf = N.child[k];
+                    if (nf == 0) f0 = leaf; else if (nf == 1) f1 = leaf; else if (nf == 2) f2 = leaf; else f3 = leaf;
+                    ++nf;
                 } else {
-                    if (sp >= kStack) { too_many = true; break; }
-                    st[sp++] = N.child[k];
+                    if (sp >= A.stack_cap) { too_many = true; break; }
+                    stk.push(sp, N.child[k]);
                 }
             }
         }
         if (too_many) break;
-        out.x = nf > 0 ? found[0] : rtk::kNone; out.y = nf > 1 ? found[1] : rtk::kNone; out.z = nf > 2 ? found[2] : rtk::kNone; out.w = nf > 3 ? found[3] : rtk::kNone;
+        out = make_uint4(f0, f1, f2, f3);
         kind = nf == 0 ? 2 : (tmax < 1e299 ? 0 : 1);
     } while (false);
     A.lists[(size_t)ly * A.p.width + x] = out;
-    if (A.counts) atomicAdd(&A.counts[kind], 1u);
+    if (A.counts) {                                                     // one atomic per kind and wave
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long m = rtk::ballot_(kind == k);
+            if (m != 0ull && (unsigned)__builtin_ctzll(m) == (threadIdx.x & 63u)) atomicAdd(&A.counts[k], (unsigned int)__popcll(m));
+        }
+    }
 }
 
 } // namespace rtp
