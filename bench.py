@@ -402,7 +402,44 @@ def main():
                     "primitive_tests_per_s": {"box": round(sc["nodeVisits"] * 4 / (kernel_ms_rank0 / 1e3), 0),
                                               "triangle": round(sc["triTests"] / (kernel_ms_rank0 / 1e3), 0),
                                               "sphere": round(sc["sphereTests"] / (kernel_ms_rank0 / 1e3), 0)},
-                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]}, "pmc": None}
+                    "bvh": {"nodes": sc["numBvhNodes"], "max_stack": sc["bvhMaxStack"]},
+                    "camera_ray_lists": {"pixels_bounded_list": int(sc["primaryLists"][0]), "pixels_unbounded_list": int(sc["primaryLists"][1]),
+                                         "pixels_certain_miss": int(sc["primaryLists"][2]), "pixels_no_list": int(sc["primaryLists"][3]),
+                                         "build_ms": round(sc["lastPrimaryListsMs"], 3), "builds": int(sc["primaryListBuilds"]),
+                                         "note": "per pixel, the <= 4 BVH leaves that can hold the closest hit of its camera rays (csrc/rt_primary.hpp), built once per "
+                                                 "camera / scene before the warm-up — an acceleration structure like the BVH, outside the timed region; every ray is still traced"},
+                    "pmc": None}
+        # ---- the launch's VALU instruction count from THIS run's own counting pass: wave-level executions of every region of k_stream
+        # (rt_stats.phaseExecs / schedExecs) x the region's static VALU count from the code object's assembly (tools/static_valu.py ->
+        # static_valu.json, stamped with the source hash).  An independent figure next to the stored rocprofv3 one: they must agree.
+        valu_model = None
+        sv_path = os.path.join(ROOT, "ray-tracing-extended_amd", "static_valu.json")
+        if kernel_name.startswith("k_stream") and os.path.exists(sv_path):
+            try:
+                sv = json.load(open(sv_path))
+            except Exception:
+                sv = {}
+            key = kernel_name.replace("k_stream<false,false,true>", "k_stream<false,false,true,true>").replace("k_stream<false,true,true>", "k_stream<false,true,true,true>") \
+                             .replace("k_stream<false,false,false>", "k_stream<false,false,false,true>").replace("k_stream<false,true,false>", "k_stream<false,true,false,true>")
+            ent_sv = (sv.get("kernels") or {}).get(key)
+            if ent_sv and sc.get("schedExecs"):
+                v = ent_sv["valu"]
+                se = sc["schedExecs"]
+                n_shade, n_leaf, n_burst, n_biter, n_nloop, n_fetch = (float(x) for x in se)
+                total = (v["loop"] * (n_shade + n_burst + n_fetch) + v["fetch"] * n_fetch + v["shade"] * n_shade + v["hit"] * execs["shade"]
+                         + v["env"] * execs["environment"] + v["camera"] * execs["camera"] + v["burst"] * n_burst + v["burstiter"] * n_biter
+                         + v["nodeloop"] * n_nloop + v["node"] * execs["node"] + v["leaf"] * n_leaf + v["tri"] * execs["triangle"])
+                valu_model = {"valu_wave_instructions_per_frame": round(total / max(args.steps, 1), 0),
+                              "regions_static_valu": v, "region_execs_per_frame": {
+                                  "shade_passes": round(n_shade / args.steps, 1), "leaf_phases": round(n_leaf / args.steps, 1), "bursts": round(n_burst / args.steps, 1),
+                                  "burst_iterations": round(n_biter / args.steps, 1), "node_loop_iterations": round(n_nloop / args.steps, 1), "fetches": round(n_fetch / args.steps, 1),
+                                  "node_steps": round(execs["node"] / args.steps, 1), "triangle_tests": round(execs["triangle"] / args.steps, 1),
+                                  "hit_blocks": round(execs["shade"] / args.steps, 1), "environment_blocks": round(execs["environment"] / args.steps, 1),
+                                  "camera_blocks": round(execs["camera"] / args.steps, 1)},
+                              "static_csrc_sha16": sv.get("csrc_sha16"), "static_stale": sv.get("csrc_sha16") != csrc_sha16(),
+                              "note": "sum over k_stream's regions of (wave-level executions counted by this run's counting pass) x (VALU instructions of the region in the "
+                                      "code object, blocks behind cold-path markers left out); conditional sub-blocks inside a region count as executed, so this is an upper "
+                                      "estimate of SQ_INSTS_VALU"}
         if pmc:
             instr_s = pmc["valu_wave_instructions_per_frame"] * fpl / launch_s
             roofline["achieved"] = round(instr_s / 1e9, 2)
@@ -416,7 +453,14 @@ def main():
                                          "frac": round(loads_s * VMEM_CYCLES_PER_WAVE_LOAD / (256 * 2.4e9), 5)}
             roofline["pmc"] = {k: pmc.get(k) for k in ("l2_hit_rate", "l1_hit_rate", "valu_lane_utilisation", "ta_busy_frac", "td_busy_frac", "wait_any_frac_of_wave_cycles",
                                                         "wait_inst_any_frac_of_wave_cycles", "csrc_sha16", "stale", "source")}
-        else:
+            if valu_model:
+                ratio = valu_model["valu_wave_instructions_per_frame"] / max(pmc["valu_wave_instructions_per_frame"], 1.0)
+                valu_model["pmc_valu_wave_instructions_per_frame"] = round(pmc["valu_wave_instructions_per_frame"], 0)
+                valu_model["model_over_pmc"] = round(ratio, 4)
+                valu_model["agree_within_5_percent"] = bool(abs(ratio - 1.0) <= 0.05)
+                roofline["pmc"]["stale"] = bool(roofline["pmc"]["stale"] or not valu_model["agree_within_5_percent"])     # a stored count that the run's own counters contradict is stale
+        roofline["valu_model"] = valu_model
+        if not pmc:
             # no PMC pass for this configuration / kernel: the instruction counts are unknown, so no issue fraction is claimed; the HBM contract
             # figures of SURVEY 8(d) stay under `hbm` (cache-served: they can exceed the HBM peak and are not a roofline fraction)
             roofline["definition"] = ("no committed rocprofv3 --pmc pass for this configuration: achieved / frac are not claimed (tools/profile.sh + "

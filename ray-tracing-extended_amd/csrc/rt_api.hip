@@ -144,7 +144,7 @@ struct rt_ctx {
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     DevBuf<uint32_t> d_gstack;
     // camera rays' candidate lists (rt_primary.hpp): valid for one (params, rows, scene) combination
-    DevBuf<uint4> d_primary; DevBuf<unsigned int> d_primary_counts;
+    DevBuf<uint4> d_primary; DevBuf<float4> d_focus; DevBuf<unsigned int> d_primary_counts;
     std::string primary_key;                        // what the lists were built for (parameters, rows, scene version)
     unsigned long long scene_version = 0;           // bumped whenever the tree or its boxes change (build, refit, re-padding)
     int opt_primary_lists = 1;                      // 1: camera rays of a static camera start from their pixel's candidate leaves (k_stream); 0: always from the root
@@ -763,11 +763,11 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         const bool eligible = stream && c->opt_primary_lists && c->n_nodes > 0 && F.fixed_origin && c->target_pixels > 0 && c->bvh.maxStack <= 160;
         if (eligible) {                 // (the build takes well under a millisecond at 1080p: a camera that moves every frame pays it every frame and still gains)
             if (key != c->primary_key) {
-                RT_HIP(c, c->d_primary.ensure(c->target_pixels)); RT_HIP(c, c->d_primary_counts.ensure(4));
+                RT_HIP(c, c->d_primary.ensure(c->target_pixels)); RT_HIP(c, c->d_focus.ensure(c->target_pixels)); RT_HIP(c, c->d_primary_counts.ensure(4));
                 RT_HIP(c, hipMemsetAsync(c->d_primary_counts.p, 0, 4 * sizeof(unsigned int), c->stream));
                 rtp::PrimaryArgs PA{};
                 PA.p = c->params; PA.row0 = c->target_row0; PA.nrows = c->target_rows; PA.row_stride = c->target_row_stride;
-                PA.lists = c->d_primary.p; PA.counts = c->d_primary_counts.p;
+                PA.lists = c->d_primary.p; PA.focus = c->d_focus.p; PA.counts = c->d_primary_counts.p;
                 const int tiles = ((c->target_w + 7) / 8) * ((c->target_rows + 7) / 8);
                 PA.stack_cap = std::max(1, c->bvh.maxStack);                       // (the whole worst case in LDS: at most 160 entries x 64 lanes x 4 B = 40 KB per wave)
                 const size_t plds = (size_t)PA.stack_cap * 64 * sizeof(uint32_t);
@@ -784,7 +784,7 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
                 c->stats.lastPrimaryListsMs = ms; c->stats.primaryListBuilds++;
                 c->primary_key = key;
             }
-            F.primary = c->d_primary.p;
+            F.primary = c->d_primary.p; F.focus = c->d_focus.p;
         }
     }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, rtk::kNumCounters * sizeof(unsigned long long), c->stream));
@@ -1046,7 +1046,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_sph_geom.release(); c->d_sph_mat.release(); c->d_nodes.release(); c->d_nodes_h.release(); c->d_tri_geo.release(); c->d_tri_nrm.release();
     c->d_chunk_mat.release(); c->d_chunk_box.release(); c->d_raw_tris.release(); c->d_raw_range.release();
-    c->d_primary.release(); c->d_primary_counts.release();
+    c->d_primary.release(); c->d_focus.release(); c->d_primary_counts.release();
     c->d_frame.release(); c->d_accum.release(); c->d_gstack.release(); c->d_park.release(); c->d_display.release(); c->d_batch.release(); c->d_tile_order.release(); c->d_tile_cost.release(); c->d_tile_hist.release();
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
     if (c->d_counters) (void)hipFree(c->d_counters);

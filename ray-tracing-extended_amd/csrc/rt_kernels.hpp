@@ -63,6 +63,7 @@ struct FrameArgs {
     float* park;                // k_stream, Philox mode: per wave [items of a group][3][64] sub-stream sums waiting for the estimator's tree; else null
     const uint4* primary;       // k_stream: per local pixel, up to four leaf references a camera ray of that pixel starts with instead of the root
                                 // (rt_primary.hpp: .x = 0xFFFFFFFE no list, kNone-terminated, all kNone = certain miss); null = every ray starts at the root
+    const float4* focus;        // k_stream: per local pixel its focus point, computed once with the lists (the same float operations as the camera block's); null = compute
     unsigned int* tile_counter;
     unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5], sched[6]
 };
@@ -110,8 +111,10 @@ constexpr int kNumCounters = 21;
 // compile of that tool defines RT_MARKERS; the product library is built without them.
 #ifdef RT_MARKERS
 #define RT_MARK(TEXT) asm volatile("; RTMARK " TEXT)
+#define RT_RARE_PATH() asm volatile("; RTRARE")      /* a block the benchmark configurations do not execute (option off, stack within its LDS part) */
 #else
 #define RT_MARK(TEXT) do { } while (0)
+#define RT_RARE_PATH() do { } while (0)
 #endif
 
 template <bool COUNT>
@@ -301,7 +304,7 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, uint
     // the nearest child must come first; a full sort of the other three (2 more exchanges) only refines the order in
     // which they are popped later
     RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2)
-    if (full_sort) { RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2) }
+    if (full_sort) { RT_RARE_PATH(); RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2) }
 #undef RT_CSWAP
 }
 

@@ -68,6 +68,7 @@ struct PrimaryArgs {
     rt_params p;
     int row0, nrows, row_stride;        // as FrameArgs: local row ly -> global row row0 + (ly / 8) * row_stride + ly % 8
     uint4* lists;                       // [nrows * width]
+    float4* focus;                      // [nrows * width] the pixel's focus point (frag :364-366), which every one of its camera rays needs again
     int stack_cap;                      // LDS stack entries per lane (the BVH's worst case)
     unsigned int* counts;               // [4] pixels with a list bounded by a common triangle, with an unbounded list, certainly missing everything, without a list
 };
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(64) void k_primary_lists(rtk::DeviceScene S, Primar
         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
         const float fpx = ((M[0] * lx + M[1] * lyv) + M[2] * lz) + M[3] * 1.0f, fpy = ((M[4] * lx + M[5] * lyv) + M[6] * lz) + M[7] * 1.0f,
                     fpz = ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f;
+        A.focus[(size_t)ly * A.p.width + x] = make_float4(fpx, fpy, fpz, 0.0f);
         const D3 fp{ fpx, fpy, fpz }, right{ M[0], M[4], M[8] }, up{ M[1], M[5], M[9] };
         const D3 pos{ p.worldSpaceCameraPos[0], p.worldSpaceCameraPos[1], p.worldSpaceCameraPos[2] };
         // footprint: |jitter| <= |DivergeStrength| / width in both basis directions (RandomPointInCircle has radius <= 1; its sqrt / cos / sin

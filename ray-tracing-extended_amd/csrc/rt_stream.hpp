@@ -466,11 +466,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         cam.pos   = ld3(p.worldSpaceCameraPos);
                         const int px = (int)(pxy & 0xFFFFu), ly = (int)(pxy >> 16);
                         const int y = F.row0 + (ly >> 3) * F.row_stride + (ly & 7);
+#ifdef RT_AB_NO_FOCUS      /* A/B builds only (tools/build_variant.py) */
+                        if (false) {
+#else
+                        if (F.focus != nullptr) {
+#endif
+                            // a pixel's focus point is the same for all its samples: read what k_primary_lists computed (the operations below, once)
+                            const float4 fpt = F.focus[(size_t)ly * W + (uint32_t)px];
+                            cam.focusPoint = rtm::mk(fpt.x, fpt.y, fpt.z);
+                        } else {
                         const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
                         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,
                                                  ((M[4] * lx + M[5] * lyv) + M[6]  * lz) + M[7]  * 1.0f,
                                                  ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f);
+                        }
                         if constexpr (PHILOX) {
                             rtm::PhiloxScope R;                                        // the four draws of this sample's camera ray: block 0
                             R.begin((uint32_t)y * W + (uint32_t)px, (uint32_t)F.frame + (kidx >> 16), (uint32_t)sample & 0xFFFFu, 0u);
@@ -565,6 +575,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             slot(top) = c1; top = (t1 < INF) ? top + 256u : top;
                         } else {
                             // some lane is within three entries of the LDS part: checked pushes, spilling past it
+                            RT_RARE_PATH();
                             auto push = [&](uint32_t c) {
                                 const uint32_t depth = top - stk0;
                                 if (depth < capb) slot(top) = c; else gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride] = c;

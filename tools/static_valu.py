@@ -71,36 +71,56 @@ def kernels(text):
 
 
 def count(lines, marked):
-    regions = {r: {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0} for r in REGIONS}
-    cold = {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0}
-    stack, in_cold, problems = ["loop"], False, []
+    """per region: instructions of the blocks that run on real inputs.  The function body is cut into basic blocks (labels and the
+    assembler's `; %bb.N:` comments); a block that holds an RTCOLD / RTRARE comment is cold, and so is everything after it up to the label
+    that the branch in front of it jumps to (a slow path may span several blocks: a division's expansion)."""
+    blocks, cur = [], {"label": "entry", "lines": []}
     for ln in lines:
         t = ln.strip()
         if not t:
             continue
-        if re.match(r"^\.LBB\d+_\d+:", t):
-            in_cold = False                      # a cold block ends at the next label
+        m = re.match(r"^(\.LBB\d+_\d+):", t) or re.match(r"^; (%bb\.\d+):", t)
+        if m:
+            blocks.append(cur)
+            cur = {"label": m.group(1), "lines": []}
             continue
-        m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
-        if m and marked:
-            if m.group(1) == "begin":
-                stack.append(m.group(2))
-            elif len(stack) > 1 and stack[-1] == m.group(2):
-                stack.pop()
-            else:
-                problems.append(f"end {m.group(2)} while in {stack[-1]}")
-                while len(stack) > 1 and stack[-1] != m.group(2):
+        cur["lines"].append(t)
+    blocks.append(cur)
+    # cold blocks
+    prev_skip = None
+    for i, b in enumerate(blocks):
+        if not b.get("cold") and any(t.startswith(("; RTCOLD", "; RTRARE")) for t in b["lines"]):
+            b["cold"] = True
+            # the skip branch that ends the block in front names the join label: cold up to it when it follows within a few blocks
+            ahead = [blocks[j]["label"] for j in range(i + 1, min(i + 8, len(blocks)))]
+            if prev_skip in ahead:
+                for j in range(i + 1, i + 1 + ahead.index(prev_skip)):
+                    blocks[j]["cold"] = True
+        code = [t for t in b["lines"] if not t.startswith((";", "."))]
+        m = re.match(r"^s_cbranch_exec\w*\s+(\.LBB\d+_\d+)", code[-1]) if code else None
+        prev_skip = m.group(1) if m else None
+    regions = {r: {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0} for r in REGIONS}
+    cold = {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0}
+    stack, problems = ["loop"], []
+    for b in blocks:
+        for t in b["lines"]:
+            m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
+            if m and marked:
+                if m.group(1) == "begin":
+                    stack.append(m.group(2))
+                elif len(stack) > 1 and stack[-1] == m.group(2):
                     stack.pop()
-                if len(stack) > 1:
-                    stack.pop()
-            continue
-        if t.startswith("; RTCOLD"):
-            in_cold = True
-            continue
-        if t.startswith((";", ".")):
-            continue
-        k = kind(t.split()[0])
-        (cold if in_cold else regions[stack[-1]])[k] += 1
+                else:
+                    problems.append(f"end {m.group(2)} while in {stack[-1]}")
+                    while len(stack) > 1 and stack[-1] != m.group(2):
+                        stack.pop()
+                    if len(stack) > 1:
+                        stack.pop()
+                continue
+            if t.startswith((";", ".")):
+                continue
+            k = kind(t.split()[0])
+            (cold if b.get("cold") else regions[stack[-1]])[k] += 1
     return regions, cold, problems
 
 
