@@ -422,24 +422,20 @@ def main():
             key = kernel_name.replace("k_stream<false,false,true>", "k_stream<false,false,true,true>").replace("k_stream<false,true,true>", "k_stream<false,true,true,true>") \
                              .replace("k_stream<false,false,false>", "k_stream<false,false,false,true>").replace("k_stream<false,true,false>", "k_stream<false,true,false,true>")
             ent_sv = (sv.get("kernels") or {}).get(key)
-            if ent_sv and sc.get("schedExecs"):
+            if ent_sv and sc.get("regionExecs"):
                 v = ent_sv["valu"]
-                se = sc["schedExecs"]
-                n_shade, n_leaf, n_burst, n_biter, n_nloop, n_fetch = (float(x) for x in se)
-                total = (v["loop"] * (n_shade + n_burst + n_fetch) + v["fetch"] * n_fetch + v["shade"] * n_shade + v["hit"] * execs["shade"]
-                         + v["env"] * execs["environment"] + v["camera"] * execs["camera"] + v["burst"] * n_burst + v["burstiter"] * n_biter
-                         + v["nodeloop"] * n_nloop + v["node"] * execs["node"] + v["leaf"] * n_leaf + v["tri"] * execs["triangle"])
+                names = sv.get("regions") or []
+                ex = {n: float(sc["regionExecs"][i]) for i, n in enumerate(names) if i < len(sc["regionExecs"])}
+                ex["loop"] = ex.get("shade", 0.0) + ex.get("burst", 0.0) + ex.get("fetch", 0.0)          # one pass of the persistent loop's head per region entered
+                sun_off = float(params["sunIntensity"]) == 0.0 and not np.signbit(params["sunIntensity"]) and 1.0 <= float(params["sunFocus"]) <= 1.0e6
+                ex["env_sun"] = 0.0 if (sun_off or not int(params["environmentEnabled"])) else ex.get("env", 0.0)   # (a wave-uniform branch on the parameters)
+                total = sum(v.get(n, 0) * ex.get(n, 0.0) for n in names)
                 valu_model = {"valu_wave_instructions_per_frame": round(total / max(args.steps, 1), 0),
-                              "regions_static_valu": v, "region_execs_per_frame": {
-                                  "shade_passes": round(n_shade / args.steps, 1), "leaf_phases": round(n_leaf / args.steps, 1), "bursts": round(n_burst / args.steps, 1),
-                                  "burst_iterations": round(n_biter / args.steps, 1), "node_loop_iterations": round(n_nloop / args.steps, 1), "fetches": round(n_fetch / args.steps, 1),
-                                  "node_steps": round(execs["node"] / args.steps, 1), "triangle_tests": round(execs["triangle"] / args.steps, 1),
-                                  "hit_blocks": round(execs["shade"] / args.steps, 1), "environment_blocks": round(execs["environment"] / args.steps, 1),
-                                  "camera_blocks": round(execs["camera"] / args.steps, 1)},
+                              "regions_static_valu": v, "region_execs_per_frame": {n: round(ex.get(n, 0.0) / max(args.steps, 1), 1) for n in names},
                               "static_csrc_sha16": sv.get("csrc_sha16"), "static_stale": sv.get("csrc_sha16") != csrc_sha16(),
-                              "note": "sum over k_stream's regions of (wave-level executions counted by this run's counting pass) x (VALU instructions of the region in the "
-                                      "code object, blocks behind cold-path markers left out); conditional sub-blocks inside a region count as executed, so this is an upper "
-                                      "estimate of SQ_INSTS_VALU"}
+                              "note": "sum over k_stream's regions (csrc/rt_kernels.hpp RT_REGION_LIST) of (wave-level executions counted by this run's counting pass, "
+                                      "rt_stats.regionExecs) x (VALU instructions of the region in the code object's assembly, tools/static_valu.py; blocks behind "
+                                      "cold-path markers left out)"}
         if pmc:
             instr_s = pmc["valu_wave_instructions_per_frame"] * fpl / launch_s
             roofline["achieved"] = round(instr_s / 1e9, 2)

@@ -164,10 +164,10 @@ typedef struct rt_stats {
                                            boxes were padded for: refit of the existing tree, no rebuild, no re-upload)   */
     int32_t  lastSampleLanes;           /* Philox mode: lanes of a wave that shared a pixel's samples in the last launch (16, 4 or 1) */
     int32_t  queuedLaunches;            /* launches the rt_submit_frame queue has made since rt_reset_accum                */
-    uint64_t schedExecs[6];             /* rt_render_counting, k_stream: wave-level executions of its scheduling regions — 0 SHADE passes, */
-                                        /* 1 leaf phases, 2 traversal bursts, 3 outer iterations of the bursts, 4 node-loop iterations,   */
-                                        /* 5 group fetches (with phaseExecs and the regions' static instruction counts: the launch's     */
-                                        /* VALU instruction count without a profiler, bench.py roofline.valu_model)                      */
+    uint64_t regionExecs[32];           /* rt_render_counting, k_stream: wave-level executions of its regions, in the order of csrc/rt_kernels.hpp      */
+                                        /* RT_REGION_LIST (loop, fetch, shade, hit, ...).  Multiplied with the regions' static VALU counts (from the code */
+                                        /* object's assembly, tools/static_valu.py) they give the launch's VALU instruction count without a profiler:      */
+                                        /* bench.py roofline.valu_model                                                                                   */
     uint32_t primaryLists[4];           /* camera rays' candidate lists of the last build (k_stream, static camera): pixels whose camera rays  */
                                         /* start from <= 4 leaves bounded by a common triangle / from an unbounded list / certainly miss         */
                                         /* everything / start at the root (no list)                                                              */

@@ -42,7 +42,7 @@ STATS = np.dtype([
     ("lastKernelMs", "<f8"), ("totalKernelMs", "<f8"), ("lastGeometryMs", "<f8"), ("lastDisplayMs", "<f8"), ("lastFramesPerLaunch", "<i4"), ("autoKernel", "<i4"),
     ("lastKernel", "<i4"), ("lastFramesInterleaved", "<i4"),
     ("lastBvhBuildMs", "<f8"), ("refitAreaRatio", "<f4"), ("bvhInternalArea", "<f4"), ("bvhBuiltOnDevice", "<i4"), ("bvhBuilds", "<i4"),
-    ("bvhRebuilds", "<i4"), ("bvhRepads", "<i4"), ("lastSampleLanes", "<i4"), ("queuedLaunches", "<i4"), ("schedExecs", "<u8", 6),
+    ("bvhRebuilds", "<i4"), ("bvhRepads", "<i4"), ("lastSampleLanes", "<i4"), ("queuedLaunches", "<i4"), ("regionExecs", "<u8", 32),
     ("primaryLists", "<u4", 4), ("primaryListBuilds", "<i4"), ("_reserved", "<i4"), ("lastPrimaryListsMs", "<f8"),
 ])
 MESH_TRANSFORM = np.dtype([("position", "<f4", 3), ("rotation", "<f4", 4), ("lossyScale", "<f4", 3)])

@@ -853,11 +853,11 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
         if (var == Variant::Counting) {
             c->stats.sphereTests = h[1]; c->stats.nodeVisits = h[2]; c->stats.triTests = h[3]; c->stats.hits = h[4];
             for (int k = 0; k < 5; ++k) { c->stats.phaseLanes[k] = h[5 + k]; c->stats.phaseExecs[k] = h[10 + k]; }
-            for (int k = 0; k < 6; ++k) c->stats.schedExecs[k] = h[15 + k];
+            for (int k = 0; k < rtk::kNumRegions; ++k) c->stats.regionExecs[k] = h[15 + k];
         } else {
             c->stats.sphereTests = c->stats.nodeVisits = c->stats.triTests = c->stats.hits = 0;
             for (int k = 0; k < 5; ++k) c->stats.phaseLanes[k] = c->stats.phaseExecs[k] = 0;
-            for (int k = 0; k < 6; ++k) c->stats.schedExecs[k] = 0;
+            for (int k = 0; k < rtk::kNumRegions; ++k) c->stats.regionExecs[k] = 0;
         }
     }
     return 0;
@@ -897,7 +897,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         const rt_stats& s = c->stats;
         sum.rays += s.rays; sum.sphereTests += s.sphereTests; sum.nodeVisits += s.nodeVisits; sum.triTests += s.triTests; sum.hits += s.hits;
         for (int k = 0; k < 5; ++k) { sum.phaseLanes[k] += s.phaseLanes[k]; sum.phaseExecs[k] += s.phaseExecs[k]; }
-        for (int k = 0; k < 6; ++k) sum.schedExecs[k] += s.schedExecs[k];
+        for (int k = 0; k < rtk::kNumRegions; ++k) sum.regionExecs[k] += s.regionExecs[k];
         sum.lastKernelMs += s.lastKernelMs; any = true;
     };
     int done = 0;
@@ -927,7 +927,7 @@ int launch_frames(rt_ctx* c, int first_frame, int n_frames, Variant var)
         c->stats.rays = sum.rays; c->stats.sphereTests = sum.sphereTests; c->stats.nodeVisits = sum.nodeVisits;
         c->stats.triTests = sum.triTests; c->stats.hits = sum.hits;
         for (int k = 0; k < 5; ++k) { c->stats.phaseLanes[k] = sum.phaseLanes[k]; c->stats.phaseExecs[k] = sum.phaseExecs[k]; }
-        for (int k = 0; k < 6; ++k) c->stats.schedExecs[k] = sum.schedExecs[k];
+        for (int k = 0; k < rtk::kNumRegions; ++k) c->stats.regionExecs[k] = sum.regionExecs[k];
         c->stats.lastKernelMs = sum.lastKernelMs;
     }
     c->stats.autoKernel = c->auto_choice;
@@ -1643,7 +1643,7 @@ int rt_multi_get_stats(rt_multi* m, rt_stats* out, double* gather_ms)
         const rt_stats& s = m->ctx[i]->stats;
         sum.rays += s.rays; sum.sphereTests += s.sphereTests; sum.nodeVisits += s.nodeVisits; sum.triTests += s.triTests; sum.hits += s.hits;
         for (int k = 0; k < 5; ++k) { sum.phaseLanes[k] += s.phaseLanes[k]; sum.phaseExecs[k] += s.phaseExecs[k]; }
-        for (int k = 0; k < 6; ++k) sum.schedExecs[k] += s.schedExecs[k];
+        for (int k = 0; k < rtk::kNumRegions; ++k) sum.regionExecs[k] += s.regionExecs[k];
         sum.lastKernelMs = std::max(sum.lastKernelMs, s.lastKernelMs); sum.totalKernelMs = std::max(sum.totalKernelMs, s.totalKernelMs);
     }
     *out = sum;

@@ -65,7 +65,7 @@ struct FrameArgs {
                                 // (rt_primary.hpp: .x = 0xFFFFFFFE no list, kNone-terminated, all kNone = certain miss); null = every ray starts at the root
     const float4* focus;        // k_stream: per local pixel its focus point, computed once with the lists (the same float operations as the camera block's); null = compute
     unsigned int* tile_counter;
-    unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5], sched[6]
+    unsigned long long* counters;   // [kNumCounters] rays, sphereTests, nodeVisits, triTests, hits, phase lanes[5], phase execs[5], region[32]
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -101,11 +101,23 @@ __device__ __forceinline__ unsigned long long ballot_(bool pred) { return __buil
 // lowered through a VGPR again)
 __device__ __forceinline__ unsigned long long ballot2_(bool a, bool b) { return __builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b); }
 
-// sched[k] (k_stream, counting build): wave-level executions of the scheduling regions — 0 SHADE passes, 1 leaf phases, 2 traversal bursts,
-// 3 iterations of a burst's outer loop, 4 iterations of its node loop, 5 group fetches.  With the static VALU count of every region
-// (tools/static_valu.py, from the code object's assembly) they give the launch's VALU instruction count without a profiler pass.
-struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; uint32_t sched[6]; };
-constexpr int kNumCounters = 21;
+// Regions of k_stream (rt_stream.hpp).  The counting build counts how often a wave executes each of them (Counters::region,
+// rt_stats.regionExecs); tools/static_valu.py counts the VALU instructions of each in the code object's assembly — the product of the two
+// is the launch's VALU instruction count without a profiler pass (bench.py roofline.valu_model).  A region is what lies between
+// RT_REGION_BEGIN and RT_REGION_END in the source; the innermost region owns an instruction.  `loop` is everything outside the others.
+#define RT_REGION_LIST(X) X(loop) X(fetch) X(shade) X(hit) X(hit_sphere) X(hit_checker) X(hit_scatter) X(env) X(env_sun) X(camera) X(pixel_done) \
+                          X(take) X(refill) X(setup) X(setup_list) X(burst) X(burstiter) X(nodeloop) X(node) X(node_spill) X(node_pop) X(leaf) X(tri) \
+                          X(tri_accept) X(tri_tie) X(tri_chunk)
+enum Region : int {
+#define RT_X(NAME) R_##NAME,
+    RT_REGION_LIST(RT_X)
+#undef RT_X
+    kRegionsUsed
+};
+constexpr int kNumRegions = 32;
+static_assert(kRegionsUsed <= kNumRegions, "rt_stats.regionExecs holds 32 regions");
+struct Counters { uint32_t rays, sph, nodes, tris, hits; uint32_t phase_lanes[5], phase_execs[5]; uint32_t region[kNumRegions]; };
+constexpr int kNumCounters = 15 + kNumRegions;
 
 // Region markers for tools/static_valu.py: an assembler comment in a side-effect asm statement (it assembles to nothing).  Only the -S
 // compile of that tool defines RT_MARKERS; the product library is built without them.
@@ -116,6 +128,10 @@ constexpr int kNumCounters = 21;
 #define RT_MARK(TEXT) do { } while (0)
 #define RT_RARE_PATH() do { } while (0)
 #endif
+// (COUNT and cnt are the enclosing kernel's; the tick is one increment on the first active lane, in the counting build only)
+#define RT_REGION_BEGIN(NAME) do { RT_MARK("begin " #NAME); if (COUNT) { const unsigned long long rm_ = rtk::ballot_(true); \
+                                   if ((unsigned)__builtin_ctzll(rm_) == (threadIdx.x & 63u)) cnt.region[rtk::R_##NAME]++; } } while (0)
+#define RT_REGION_END(NAME) RT_MARK("end " #NAME)
 
 template <bool COUNT>
 __device__ __forceinline__ void phase_tick(Counters& cnt, int k)
@@ -471,8 +487,12 @@ __device__ __forceinline__ v3 environment_light(const rt_params& p, v3 d)
     v3 skyGradient = rtm::lerp(ld3(p.skyColourHorizon), ld3(p.skyColourZenith), skyGradientT);
     // sunIntensity == +0 (e.g. Chess.unity:30185): the base max(0, dot) is finite, >= 0 and at most 1 + a few ulp, so for
     // 1 <= sunFocus <= 1e6 pow() is finite and >= 0 and the product is exactly +0; skip the transcendentals, keep the adds.
-    float sun = (__float_as_uint(p.sunIntensity) == 0u && p.sunFocus >= 1.0f && p.sunFocus <= 1.0e6f) ? 0.0f
-              : rtm::pow_(rtm::fmax_(0.0f, rtm::dot(d, ld3(p.worldSpaceLightPos0))), p.sunFocus) * p.sunIntensity;
+    float sun = 0.0f;
+    if (!(__float_as_uint(p.sunIntensity) == 0u && p.sunFocus >= 1.0f && p.sunFocus <= 1.0e6f)) {     // (wave-uniform: parameters only)
+        RT_MARK("begin env_sun");
+        sun = rtm::pow_(rtm::fmax_(0.0f, rtm::dot(d, ld3(p.worldSpaceLightPos0))), p.sunFocus) * p.sunIntensity;
+        RT_MARK("end env_sun");
+    }
     v3 composite = rtm::lerp(ld3(p.groundColour), skyGradient, groundToSkyT);
     float sunTerm = sun * ((groundToSkyT >= 1.0f) ? 1.0f : 0.0f);
     return rtm::mk(composite.x + sunTerm, composite.y + sunTerm, composite.z + sunTerm);
@@ -699,7 +719,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES ==
     {
         unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
         for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
-        for (int k = 0; k < 6; ++k) v[15 + k] = cnt.sched[k];
+        for (int k = 0; k < kNumRegions; ++k) v[15 + k] = cnt.region[k];
         for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

@@ -207,8 +207,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
         const int nTrav = __popcll(ballot_(mode == kModeTrav)), nShade = __popcll(ballot_(mode == kModeShade));
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
-            RT_MARK("begin fetch");
-            if (COUNT && lane == 0) cnt.sched[5]++;
+            RT_REGION_BEGIN(fetch);
             // ---- the whole wave is done with its group of tiles: reserve the next group (work items in LPT order)
             const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             }
             next_unit = 0;
             if (take_units(F, A, true)) { fresh = true; mode = kModeShade; }
-            RT_MARK("end fetch");
+            RT_REGION_END(fetch);
             continue;
         }
 
@@ -307,8 +306,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             // shading waves fill the gaps: +4.5 % / +3.3 % on the two triangle workloads (0/0: 12.86, trav 1 / shade 0: 13.44,
             // trav 0 / shade 1: 12.91, node loop 2 / leaves 1 / shade 0: 13.44 Grays/s).
             __builtin_amdgcn_s_setprio(0);
-            RT_MARK("begin shade");
-            if (COUNT && lane == 0) cnt.sched[0]++;
+            RT_REGION_BEGIN(shade);
             const StreamKernArgs& KA = fresh_kernargs<StreamKernArgs>();
             const DeviceScene& S = KA.S; const FrameArgs& F = KA.F; const StreamArgs& A = KA.A;
             const rt_params& p = F.p;
@@ -323,7 +321,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                 if (live) {
                     if (best.id != kNone) {
                         // ---- hit: Trace :309-343
-                        RT_MARK("begin hit");
+                        RT_REGION_BEGIN(hit);
                         phase_tick<COUNT>(cnt, 2);
                         if (COUNT) cnt.hits++;
                         const v3 hitPoint = o + d * best.t;
@@ -337,22 +335,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                                                     + rtm::mk(n2.x, n2.y, n2.z) * best.v);
                             mat = S.chunk_mat + (size_t)__float_as_uint(n0.w) * 4;
                         } else {
+                            RT_REGION_BEGIN(hit_sphere);
                             const float4 s = S.sph_geom[best.id];
                             normal = rtm::normalize(hitPoint - rtm::mk(s.x, s.y, s.z));
                             mat = S.sph_mat + (size_t)best.id * 4;
+                            RT_REGION_END(hit_sphere);
                         }
                         const float4 mcol = mat[0], memi = mat[1], mprm = mat[3];      // (specularColour: loaded where it is used, below)
                         const int flag = (int)__float_as_uint(mprm.w);
                         v3 colour = rtm::mk(mcol.x, mcol.y, mcol.z);
                         bool skip = false;
                         if (flag == 1) {                                               // CheckerPattern :313-317
+                            RT_REGION_BEGIN(hit_checker);
                             float cx = mod2(__builtin_floorf(hitPoint.x)), cz = mod2(__builtin_floorf(hitPoint.z));
                             if (!(cx == cz)) colour = rtm::mk(memi.x, memi.y, memi.z);
+                            RT_REGION_END(hit_checker);
                         } else if (flag == 2 && (PHILOX ? (sample >> 16) : bounce) == 0) {   // InvisibleLightSource :318-322
                             o = hitPoint + d * 0.001f;
                             skip = true;
                         }
                         if (!skip) {
+                            RT_REGION_BEGIN(hit_scatter);
                             auto scatter = [&](auto& R) {
                                 const bool isSpecular = mprm.z >= rtm::random_value(R);    // :325
                                 const float specF = isSpecular ? 1.0f : 0.0f;
@@ -373,18 +376,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                                 R.begin(pixel_index(F), (uint32_t)F.frame + (kidx >> 16), (uint32_t)sample & 0xFFFFu, 1u + 2u * ((uint32_t)sample >> 16));
                                 scatter(R);
                             } else scatter(rng);
+                            RT_REGION_END(hit_scatter);
                         }
                         if constexpr (PHILOX) { sample += 0x10000; if ((sample >> 16) > p.maxBounceCount) path_done = true; }
                         else { ++bounce; if (bounce > p.maxBounceCount) path_done = true; }   // loop bound :305
-                        RT_MARK("end hit");
+                        RT_REGION_END(hit);
                     } else {
-                        RT_MARK("begin env");
+                        RT_REGION_BEGIN(env);
 #if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 3);
 #endif
                         light = light + environment_light(p, d) * rayColour;           // :346-347
                         path_done = true;
-                        RT_MARK("end env");
+                        RT_REGION_END(env);
                     }
                     if (path_done) {
                         total = total + light;                                         // :384
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             pxy = kNoPixel; want = true;
                         } else if (sample >= p.numRaysPerPixel) {
                             // ---- pixel complete: frag :387-388 + Accumulate.shader:45-50
+                            RT_REGION_BEGIN(pixel_done);
                             const float n = (float)p.numRaysPerPixel;
                             const float cx = total.x / n, cy = total.y / n, cz = total.z / n;
                             const size_t pi = (size_t)(pxy >> 16) * W + (pxy & 0xFFFFu);
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                                 F.accum[pi] = acc;
                             }
                             pxy = kNoPixel; want = A.tile_sync != 0;
+                            RT_REGION_END(pixel_done);
                         } else need_ray = true;
                     }
                     live = false;
@@ -422,14 +428,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             }
             // ---- lanes that finished their unit take the group's next units (wave-uniform control flow); idle (WAIT) once the group has none left
             if (ballot_(want) != 0ull) {
+                RT_REGION_BEGIN(take);
                 const bool got = take_units(F, A, want);
                 if (want) { if (got) need_ray = true; else mode = kModeWait; }
+                RT_REGION_END(take);
             }
             if (mode == kModeShade) {
                 // ---- pixel refill: tile-major global order; indices outside the strip are skipped
                 while (!PHILOX && !A.tile_sync) {
                     const unsigned long long need = ballot_(pxy == kNoPixel && mode != kModeDead);
                     if (need == 0) break;
+                    RT_REGION_BEGIN(refill);
                     if (pxy == kNoPixel && mode != kModeDead) {
                         unsigned int base = 0;
                         const int first = __builtin_ctzll(need);
@@ -451,11 +460,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             }
                         }
                     }
+                    RT_REGION_END(refill);
                 }
                 if (mode == kModeShade) {
                     if (need_ray) {
                         // ---- frag :364-382
-                        RT_MARK("begin camera");
+                        RT_REGION_BEGIN(camera);
 #if !defined(RT_DIAG_IDLE) && !defined(RT_DIAG_PRIMARY) && !defined(RT_DIAG_TOP)
                         phase_tick<COUNT>(cnt, 4);
 #endif
@@ -488,10 +498,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         } else camera_ray(p, cam, rng, o, d, F.fixed_origin != 0);
                         if constexpr (PHILOX) sample &= 0xFFFF; else bounce = 0;
                         rayColour = rtm::mk(1.f, 1.f, 1.f); light = rtm::mk(0.f, 0.f, 0.f);
-                        RT_MARK("end camera");
+                        RT_REGION_END(camera);
                     }
                     {
                         // ---- new closest-hit query: CalculateRayCollision :256-273 (spheres in buffer order)
+                        RT_REGION_BEGIN(setup);
                         cnt.rays++;
                         best.t = INF; best.id = kNone;
                         const float a = rtm::dot(d, d);
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                                 // A camera ray of a pixel with a candidate list (rt_primary.hpp: every triangle a ray through the pixel's footprint can hit
                                 // first lies in these <= 4 leaves) starts with the leaves on its stack instead of the root: no node step at all.
                                 if (F.primary != nullptr && need_ray) {
+                                    RT_REGION_BEGIN(setup_list);
                                     const uint4 L = F.primary[(size_t)(pxy >> 16) * W + (pxy & 0xFFFFu)];
                                     if (L.x != 0xFFFFFFFEu) {
                                         cur = L.x;
@@ -519,28 +531,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                                         slot(top) = L.y; top = (L.y != kNone) ? top + 256u : top;
                                         if (L.x == kNone) mode = kModeShade;                            // nothing in the footprint's frustum: a certain miss
                                     }
+                                    RT_REGION_END(setup_list);
                                 }
                             }
                         }
+                        RT_REGION_END(setup);
                     }
                 }
             }
-            RT_MARK("end shade");
+            RT_REGION_END(shade);
         } else {
             // ================================ TRAVERSAL BURST ================================
             if constexpr (TRI) {
             __builtin_amdgcn_s_setprio(1);
-            RT_MARK("begin burst");
-            if (COUNT && lane == 0) cnt.sched[2]++;
+            RT_REGION_BEGIN(burst);
             // while-while over the lanes in flight: node steps until no lane holds an internal node, then every lane
             // tests its whole leaf.  The burst ends when all queries are complete, or as soon as `shade_threshold`
             // lanes wait for SHADE: the stragglers keep their traversal state and continue in the next burst.
             for (;;) {
-                RT_MARK("begin burstiter");
-                if (COUNT && lane == 0) cnt.sched[3]++;
+                RT_REGION_BEGIN(burstiter);
                 for (;;) {
-                    RT_MARK("begin nodeloop");
-                    if (COUNT && lane == 0) cnt.sched[4]++;
+                    RT_REGION_BEGIN(nodeloop);
                     // (cur is an internal node only while the lane traverses: every exit from kModeTrav sets cur = kNone)
                     const int nAtNode = __popcll(ballot_((int)cur >= 0));
                     if (nAtNode == 0) break;
@@ -553,7 +564,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                     }
 #endif
                     if ((int)cur >= 0) {
-                        RT_MARK("begin node");
+                        RT_REGION_BEGIN(node);
                         if (COUNT) cnt.nodes++;
                         phase_tick<COUNT>(cnt, 0);
 #ifdef RT_DIAG_TOP       // diagnostic build only (tools/diag_primary.py top): node steps at the first RT_DIAG_TOP / 4 x RT_DIAG_TOP + 1 nodes (breadth-first order)
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             slot(top) = c1; top = (t1 < INF) ? top + 256u : top;
                         } else {
                             // some lane is within three entries of the LDS part: checked pushes, spilling past it
-                            RT_RARE_PATH();
+                            RT_REGION_BEGIN(node_spill);
                             auto push = [&](uint32_t c) {
                                 const uint32_t depth = top - stk0;
                                 if (depth < capb) slot(top) = c; else gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride] = c;
@@ -584,22 +595,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             if (t3 < INF) push(c3);
                             if (t2 < INF) push(c2);
                             if (t1 < INF) push(c1);
+                            RT_REGION_END(node_spill);
                         }
                         if (t0 < INF) cur = c0;
-                        else if (top != stk0) cur = pop();
-                        else { cur = kNone; mode = kModeShade; }
-                        RT_MARK("end node");
+                        else {
+                            RT_REGION_BEGIN(node_pop);
+                            if (top != stk0) cur = pop();
+                            else { cur = kNone; mode = kModeShade; }
+                            RT_REGION_END(node_pop);
+                        }
+                        RT_REGION_END(node);
                     }
-                    RT_MARK("end nodeloop");
+                    RT_REGION_END(nodeloop);
                 }
                 if (mode == kModeTrav && (int)cur < 0) {            // a leaf = kLeafBit | first << 2 | count-1
-                    RT_MARK("begin leaf");
-                    if (COUNT && (unsigned)__builtin_ctzll(ballot_(true)) == (unsigned)lane) cnt.sched[1]++;
+                    RT_REGION_BEGIN(leaf);
                     uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
                     const uint32_t last = ti + (cur & 3u);
                     if (cur != kNone)           // (an empty child slot can never be entered by a traceable ray; never decode one)
                     for (; ti <= last; ++ti) {
-                        RT_MARK("begin tri");
+                        RT_REGION_BEGIN(tri);
                         float4 g0, g1, g2;
                         load_tri(S.tri_geo, ti, g0, g1, g2);
                         float dst, u, v;
@@ -611,39 +626,45 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         const bool hit = ray_triangle(o, d, rtm::mk(g0.x, g0.y, g0.z), rtm::mk(g0.w, g1.x, g1.y),
                                                       rtm::mk(g1.z, g1.w, g2.x), rtm::mk(g2.y, g2.z, g2.w), dst, u, v);
                         if (hit && dst <= best.t) {
+                            RT_REGION_BEGIN(tri_accept);
                             bool take = dst < best.t;
                             if (!take && (best.id & kTriBit) && best.id != kNone) {
                                 // equal dst: the reference keeps the triangle that comes first in the buffer
+                                RT_REGION_BEGIN(tri_tie);
                                 uint32_t oc = __float_as_uint(S.tri_nrm[(size_t)ti * 3 + 1].w);
                                 uint32_t ob = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3 + 1].w);
                                 take = oc < ob;
+                                RT_REGION_END(tri_tie);
                             }
                             if (take && F.p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
                                 // the reference only reaches this triangle if its chunk's box test passes (:279)
+                                RT_REGION_BEGIN(tri_chunk);
                                 uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
                                 float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
                                 take = ray_bounding_box(o, slab.inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z));
+                                RT_REGION_END(tri_chunk);
                             }
                             if (take) { best.t = dst; best.id = kTriBit | ti; best.u = u; best.v = v; }
+                            RT_REGION_END(tri_accept);
                         }
-                        RT_MARK("end tri");
+                        RT_REGION_END(tri);
                     }
                     if (top != stk0) cur = pop();
                     else { cur = kNone; mode = kModeShade; }
-                    RT_MARK("end leaf");
+                    RT_REGION_END(leaf);
                 }
-                RT_MARK("end burstiter");
+                RT_REGION_END(burstiter);
                 if (ballot_(mode == kModeTrav) == 0) break;
                 if ((int)__popcll(ballot_(mode == kModeShade)) >= thr) break;
             }
-            RT_MARK("end burst");
+            RT_REGION_END(burst);
             }       // (TRI)
         }
     }
     {
         unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
         for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
-        for (int k = 0; k < 6; ++k) v[15 + k] = cnt.sched[k];
+        for (int k = 0; k < kNumRegions; ++k) v[15 + k] = cnt.region[k];
         for (int k = 0; k < (COUNT ? kNumCounters : 1); ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

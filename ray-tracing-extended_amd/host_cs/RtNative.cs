@@ -129,7 +129,7 @@ namespace RtMi355x
         public int bvhRepads;
         public int lastSampleLanes;
         public int queuedLaunches;
-        public fixed ulong schedExecs[6];
+        public fixed ulong regionExecs[32];
         public fixed uint primaryLists[4];
         public int primaryListBuilds;
         public int _reserved;

@@ -27,7 +27,16 @@ import __graft_entry__ as g
 
 CSRC = g.CSRC
 OUT = os.path.join(ROOT, "ray-tracing-extended_amd", "static_valu.json")
-REGIONS = ("loop", "fetch", "shade", "hit", "env", "camera", "burst", "burstiter", "nodeloop", "node", "leaf", "tri")
+
+
+def region_list():
+    """the regions, in rt_stats.regionExecs order: csrc/rt_kernels.hpp RT_REGION_LIST"""
+    text = open(os.path.join(CSRC, "rt_kernels.hpp")).read()
+    body = re.search(r"#define RT_REGION_LIST\(X\)(.*?)\n(?!\s*X\()", text, re.S).group(1)
+    return tuple(re.findall(r"X\((\w+)\)", body))
+
+
+REGIONS = region_list()
 
 
 def csrc_sha16():
