@@ -426,7 +426,12 @@ def main():
                 v = ent_sv["valu"]
                 names = sv.get("regions") or []
                 ex = {n: float(sc["regionExecs"][i]) for i, n in enumerate(names) if i < len(sc["regionExecs"])}
-                ex["loop"] = ex.get("shade", 0.0) + ex.get("burst", 0.0) + ex.get("fetch", 0.0)          # one pass of the persistent loop's head per region entered
+                ex["loop"] = ex.get("shade", 0.0) + ex.get("burst", 0.0) + ex.get("fetch", 0.0)          # one pass of the persistent loop's head and latch per region entered
+                ex["head"] = ex["loop"]
+                ex["prologue"] = ex["epilogue"] = 0.0                                                    # once per wave: a few thousand waves per launch
+                dof_on = not (float(params["defocusStrength"]) == 0.0)                                   # (the host's fixed_origin decision, wave-uniform in the kernel)
+                ex["camera_dof"] = ex.get("camera", 0.0) if dof_on else 0.0
+                ex["camera_focus"] = 0.0 if int(sc["primaryLists"][0] + sc["primaryLists"][1] + sc["primaryLists"][2] + sc["primaryLists"][3]) > 0 and not dof_on else ex.get("camera", 0.0)
                 sun_off = float(params["sunIntensity"]) == 0.0 and not np.signbit(params["sunIntensity"]) and 1.0 <= float(params["sunFocus"]) <= 1.0e6
                 ex["env_sun"] = 0.0 if (sun_off or not int(params["environmentEnabled"])) else ex.get("env", 0.0)   # (a wave-uniform branch on the parameters)
                 total = sum(v.get(n, 0) * ex.get(n, 0.0) for n in names)

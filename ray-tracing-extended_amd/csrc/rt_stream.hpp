@@ -68,6 +68,7 @@ template <bool COUNT, bool PHILOX = false, bool H = false, bool TRI = true>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT_STREAM_WAVES : 6, TRI ? RT_STREAM_WAVES : 6))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
+    RT_MARK("begin prologue");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = lds_stack + (size_t)wave * F.stack_cap * 64 + lane;
     // The LDS stack holds F.stack_cap entries per lane; when the BVH's worst case is deeper (F.gstack != null) the entries
@@ -203,8 +204,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
         return got;
     };
 
+    RT_MARK("end prologue");
     for (;;) {
+        RT_MARK("begin head");
         const int nTrav = __popcll(ballot_(mode == kModeTrav)), nShade = __popcll(ballot_(mode == kModeShade));
+        RT_MARK("end head");
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             RT_REGION_BEGIN(fetch);
@@ -485,11 +489,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                             const float4 fpt = F.focus[(size_t)ly * W + (uint32_t)px];
                             cam.focusPoint = rtm::mk(fpt.x, fpt.y, fpt.z);
                         } else {
+                        RT_MARK("begin camera_focus");      // (wave-uniform: no cached focus points in this launch)
                         const float uvx = ((float)px + 0.5f) / cam.W, uvy = ((float)y + 0.5f) / (float)(uint32_t)p.height;
                         const float lx = (uvx - 0.5f) * p.viewParams[0], lyv = (uvy - 0.5f) * p.viewParams[1], lz = 1.0f * p.viewParams[2];
                         cam.focusPoint = rtm::mk(((M[0] * lx + M[1] * lyv) + M[2]  * lz) + M[3]  * 1.0f,
                                                  ((M[4] * lx + M[5] * lyv) + M[6]  * lz) + M[7]  * 1.0f,
                                                  ((M[8] * lx + M[9] * lyv) + M[10] * lz) + M[11] * 1.0f);
+                        RT_MARK("end camera_focus");
                         }
                         if constexpr (PHILOX) {
                             rtm::PhiloxScope R;                                        // the four draws of this sample's camera ray: block 0
@@ -508,10 +514,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
                         const float a = rtm::dot(d, d);
                         const SphereA sa = sphere_a(a);
                         for (int i = 0; i < S.ns; ++i) {
+                            RT_REGION_BEGIN(setup_spheres);         // (one execution per sphere and SHADE pass)
                             const float4 s = S.sph_geom[i];
                             float dst;
                             if (COUNT) cnt.sph++;
                             if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
+                            RT_REGION_END(setup_spheres);
                         }
                         live = true;
                         const bool traceable = ray_traceable(o, d, a);      // NaN / zero-direction rays are complete as they stand
@@ -661,6 +669,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             }       // (TRI)
         }
     }
+    RT_MARK("begin epilogue");
     {
         unsigned long long v[kNumCounters] = { cnt.rays, cnt.sph, cnt.nodes, cnt.tris, cnt.hits };
         for (int k = 0; k < 5; ++k) { v[5 + k] = cnt.phase_lanes[k]; v[10 + k] = cnt.phase_execs[k]; }
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT
             if (lane == 0) atomicAdd(&fresh_kernargs<StreamKernArgs>().F.counters[k], s);     // (read here: not held across the persistent loop)
         }
     }
+    RT_MARK("end epilogue");
 }
 
 } // namespace rtk

@@ -37,6 +37,7 @@ def region_list():
 
 
 REGIONS = region_list()
+OPTION_REGIONS = ("camera_dof", "camera_focus", "env_sun", "setup_spheres", "node_spill", "refill", "hit_sphere")
 
 
 def csrc_sha16():
@@ -88,10 +89,10 @@ def count(lines, marked):
         t = ln.strip()
         if not t:
             continue
-        m = re.match(r"^(\.LBB\d+_\d+):", t) or re.match(r"^; (%bb\.\d+):", t)
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", t) or re.match(r"^; (%bb\.\d+):(.*)$", t)
         if m:
             blocks.append(cur)
-            cur = {"label": m.group(1), "lines": []}
+            cur = {"label": m.group(1), "lines": [], "in_loop": "Loop" in m.group(2)}
             continue
         cur["lines"].append(t)
     blocks.append(cur)
@@ -108,9 +109,25 @@ def count(lines, marked):
         code = [t for t in b["lines"] if not t.startswith((";", "."))]
         m = re.match(r"^s_cbranch_exec\w*\s+(\.LBB\d+_\d+)", code[-1]) if code else None
         prev_skip = m.group(1) if m else None
+    # option regions — code behind a branch that is uniform for the whole launch (depth of field, spheres, sun, no cached focus points, the
+    # stack's spill path, pixel-by-pixel refill): the assembler comment can sit anywhere inside its block, so these are attributed by
+    # whole blocks, from the block that holds the `begin` comment to the label the branch in front of that block jumps to
+    prev_skip = None
+    for i, b in enumerate(blocks):
+        for t in b["lines"]:
+            m = re.match(r"^; RTMARK begin (\w+)", t)
+            if m and m.group(1) in OPTION_REGIONS and marked and "option" not in b:
+                b["option"] = m.group(1)
+                ahead = [blocks[j]["label"] for j in range(i + 1, min(i + 14, len(blocks)))]
+                if prev_skip in ahead:
+                    for j in range(i + 1, i + 1 + ahead.index(prev_skip)):
+                        blocks[j].setdefault("option", m.group(1))
+        code = [t for t in b["lines"] if not t.startswith((";", "."))]
+        m = re.match(r"^s_cbranch_\w+\s+(\.LBB\d+_\d+)", code[-1]) if code else None
+        prev_skip = m.group(1) if m else None
     regions = {r: {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0} for r in REGIONS}
     cold = {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0}
-    stack, problems = ["loop"], []
+    stack, problems, seen_loop = ["loop"], [], False
     for b in blocks:
         for t in b["lines"]:
             m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
@@ -129,7 +146,11 @@ def count(lines, marked):
             if t.startswith((";", ".")):
                 continue
             k = kind(t.split()[0])
-            (cold if b.get("cold") else regions[stack[-1]])[k] += 1
+            r = b.get("option") or stack[-1]
+            if r == "loop" and not b.get("in_loop"):            # straight-line code outside the persistent loop: before it or after it
+                r = "epilogue" if seen_loop else "prologue"
+            (cold if b.get("cold") else regions[r])[k] += 1
+        seen_loop = seen_loop or bool(b.get("in_loop"))
     return regions, cold, problems
 
 
