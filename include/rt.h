@@ -223,8 +223,9 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "bvh_collapse", "bvh_node_cost"   host builder: how the binary SAH tree becomes 4-wide nodes — 0 = greedy, open the child of largest
  *                     area (default); 1 = cost-driven dynamic programme that also forms the leaves; 2 = the same over the split search's
  *                     leaves; with a node step costing bvh_node_cost percent of a triangle test (130)
- *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS (30, with the groups' item tables = five workgroups per CU); a BVH whose worst
- *                     case is deeper spills the rest to global memory
+ *   "stream_stack"    k_stream: traversal-stack entries per lane kept in LDS; a BVH whose worst case is deeper spills the rest to global memory.
+ *                     0 (default) = automatic: 24 for the six-waves-per-SIMD instantiation (PCG stream, f16 nodes: six workgroups per CU), 30 for the
+ *                     five-wave ones (Philox mode, f32 nodes, counting build)
  *   "full_sort"       1 = sort all four children of a node by entry distance, 0 = nearest first only (default)
  *   "tile_lpt"        k_trace: 1 = hand tiles out costliest first, by the costs the previous launch measured (default), 0 = in order
  *   "frame_batch"     k_trace: frames traced per launch by rt_render (0 = auto: as many as fit 4 GiB, at most 256; 1 = one per launch)

@@ -139,8 +139,9 @@ struct rt_ctx {
     int opt_bvh_collapse = 0;       // host builder: 0 = greedy collapse of the binary tree to 4-wide nodes (open the largest child), 1 / 2 = cost-driven (bvh.cpp;
                                     // measured -4.4 % / -1.5 % on the headline scene, -1.4 % / +1.5 % on the million-triangle one: profiles/bvh_collapse_r04.txt)
     int opt_bvh_node_cost = 130;    // ... with a node step costing this many percent of a triangle test
-    int opt_stream_stack = 30;      // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory.  30 entries + the groups' item
-                                    // tables = 31,744 B per workgroup: five workgroups per CU (32,768 B already makes it four: measured -11 %)
+    int opt_stream_stack = 0;       // k_stream: stack entries per lane kept in LDS; deeper BVHs spill the rest to global memory.  0 = as many as let the
+                                    // instantiation's waves per SIMD be resident: 24 entries + the groups' item tables = 25,600 B per workgroup for the six-wave
+                                    // PCG / f16-node kernel (six workgroups per CU; 26 entries make it five: -8 %), 30 = 31,744 B for the five-wave ones
     int opt_lds_stack = 0;          // k_trace: stack entries per lane kept in LDS (0 = the BVH's worst case, nothing spills)
     DevBuf<uint32_t> d_gstack;
     // camera rays' candidate lists (rt_primary.hpp): valid for one (params, rows, scene) combination
@@ -674,8 +675,10 @@ int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int k
     if (tile_kernel && c->opt_lds_stack > 0) F.stack_cap = std::min(F.stack_cap, c->opt_lds_stack);
     if (tile_kernel) F.stack_cap = std::min(F.stack_cap, 64);        // a very deep tree spills past 64 entries instead of overflowing the LDS
     // k_stream: at most opt_stream_stack entries per lane in LDS (30 = five workgroups per CU); a deeper worst case spills
-    const bool stream_spill = stream && F.stack_cap > c->opt_stream_stack;
-    if (stream_spill) F.stack_cap = c->opt_stream_stack;
+    const bool six_waves = stream && !philox && var == Variant::Fast && c->opt_compact_nodes != 0 && c->n_nodes > 0;       // rt_stream.hpp stream_waves()
+    const int stream_stack = c->opt_stream_stack > 0 ? c->opt_stream_stack : (six_waves ? 24 : 30);
+    const bool stream_spill = stream && F.stack_cap > stream_stack;
+    if (stream_spill) F.stack_cap = stream_stack;
     F.full_sort = c->opt_full_sort;
     F.fixed_origin = camera_origin_is_fixed(c->params) ? 1 : 0;
     F.out_frame = c->d_frame.p; F.accum = c->d_accum.p;
@@ -1181,7 +1184,7 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
         c->opt_kernel = value;
     }
     else if (!std::strcmp(name, "shade_threshold")) { if (value < 1 || value > 64) return fail(c, -2, "shade_threshold must be in [1,64]"); c->opt_shade_threshold = value; }
-    else if (!std::strcmp(name, "stream_stack")) { if (value < 4 || value > 128) return fail(c, -2, "stream_stack must be in [4,128]"); c->opt_stream_stack = value; }
+    else if (!std::strcmp(name, "stream_stack")) { if (value != 0 && (value < 4 || value > 128)) return fail(c, -2, "stream_stack must be 0 (automatic) or in [4,128]"); c->opt_stream_stack = value; }
     else if (!std::strcmp(name, "lds_stack")) { if (value < 0 || value > 64) return fail(c, -2, "lds_stack must be in [0,64]"); c->opt_lds_stack = value; }
     else if (!std::strcmp(name, "bvh_bins")) { if (value < 2 || value > 128) return fail(c, -2, "bvh_bins must be in [2,128]"); if (value != c->opt_bvh_bins) c->scene_dirty = true; c->opt_bvh_bins = value; }
     else if (!std::strcmp(name, "bvh_reinsert")) { if (value < 0 || value > 16) return fail(c, -2, "bvh_reinsert must be in [0,16]"); if (value != c->opt_bvh_reinsert) c->scene_dirty = true; c->opt_bvh_reinsert = value; }

@@ -55,17 +55,20 @@ static_assert(offsetof(StreamKernArgs, F) == ((sizeof(DeviceScene) + 7) & ~size_
               && offsetof(StreamKernArgs, A) == ((offsetof(StreamKernArgs, F) + sizeof(FrameArgs) + 7) & ~size_t(7)), "kernarg layout = struct layout");
 
 template <bool COUNT, bool PHILOX = false, bool H = false, bool TRI = true>
-// Five waves per SIMD (96 VGPRs: 95 used, no scratch; LDS stack of <= 30 entries per lane so that five workgroups fit a CU): the
-// kernel hides its memory and LDS latencies with resident waves — 3 / 4 / 5 / 6 waves per SIMD gave 10.4 / 12.4 / 12.9 / 11.2 Grays/s
-// on the 100k-triangle workload when this was chosen (11.85 -> 12.75 on the million-triangle one); on the final, spill-free kernel
-// six waves (80 VGPRs, 26 dwords of scratch) measure 14.18 against 14.70 at five.
+// Waves per SIMD.  The kernel hides its memory and LDS latencies with resident waves.  Round 2 chose five (96 VGPRs; six = 80 VGPRs spilled
+// 26 dwords and lost: 14.18 against 14.70 Grays/s).  Round 4: compiled without structurizing uniform regions (__graft_entry__.py
+// STREAM_TU_FLAGS) the PCG / f16-node instantiation fits 80 VGPRs WITHOUT scratch, and six waves per SIMD — with an LDS stack of <= 24
+// entries per lane, so that six workgroups fit a CU — measure 18.3 against 17.1 Grays/s at five on the 100k-triangle workload, 16.2
+// against 15.1 on the million-triangle one (seven: 72 VGPRs + 5 dwords of scratch, 17.2; eight: 15.1).  The Philox instantiation spills
+// at 80 VGPRs (14 dwords: 13.1 against 15.8 Grays/s) and stays at five, like the f32-node and the counting instantiations.
 #ifndef RT_STREAM_WAVES
-#define RT_STREAM_WAVES 5
+#define RT_STREAM_WAVES 6
 #endif
+constexpr int stream_waves(bool count, bool philox, bool h, bool tri) { return !tri ? 6 : (count || philox || !h) ? 5 : RT_STREAM_WAVES; }
 // TRI = false: the instantiation for scenes without triangles (spheres only) — no traversal state, no burst; 76 / 86 VGPRs (PCG / Philox),
 // compiled for six waves per SIMD: 36.4 -> 39.3 (PCG; k_trace's sphere instantiation stays ahead at 41.7) and 32.6 -> 35.1 Grays/s (Philox)
 // on the sphere workload, eight waves (64 VGPRs, scratch): 37.6 / 29.7.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TRI ? RT_STREAM_WAVES : 6, TRI ? RT_STREAM_WAVES : 6))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_waves(COUNT, PHILOX, H, TRI), stream_waves(COUNT, PHILOX, H, TRI)))) void k_stream(DeviceScene S, FrameArgs F, StreamArgs A)
 {
     extern __shared__ uint32_t lds_stack[];
     RT_MARK("begin prologue");

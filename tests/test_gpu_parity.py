@@ -146,7 +146,7 @@ def test_stream_stack_spill_does_not_change_the_image(rtx, tracer, stream_stack)
         got, got_last = run_gpu(tracer, b, 2, 2, kernel=1)
         rays = tracer.stats()["rays"]
     finally:
-        tracer.set_option("stream_stack", 30)
+        tracer.set_option("stream_stack", 0)
     assert_bitwise(got_last, ref_last, f"stream(stack={stream_stack}) vs tile kernel, last frame")
     assert_bitwise(got, ref, f"stream(stack={stream_stack}) vs tile kernel, accum")
     assert rays == rays_ref
@@ -244,7 +244,7 @@ def test_philox_mode_many_frames_in_one_launch_and_every_tuning_knob(rtx, oracle
             acc, last = run_gpu(tracer, b, 0, nf, kernel=1, shade_threshold=thr)
             st = tracer.stats()
         finally:
-            tracer.set_option("compact_nodes", 1); tracer.set_option("tiles_per_fetch", 16); tracer.set_option("stream_stack", 30)
+            tracer.set_option("compact_nodes", 1); tracer.set_option("tiles_per_fetch", 16); tracer.set_option("stream_stack", 0)
         what = f"philox, {nf} frames in one launch, {rays} rays, compact_nodes={compact}, {per_fetch} items per fetch, stack {stack}, threshold {thr}"
         assert st["lastFramesPerLaunch"] == nf and st["lastSampleLanes"] == (16 if rays >= 16 else 4)
         assert_bitwise(last, want_last, what + ": last frame")
