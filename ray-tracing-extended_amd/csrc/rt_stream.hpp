@@ -54,6 +54,10 @@ static_assert(alignof(StreamArgs) <= 8, "kernarg layout = struct layout");
 static_assert(offsetof(StreamKernArgs, F) == ((sizeof(DeviceScene) + 7) & ~size_t(7))
               && offsetof(StreamKernArgs, A) == ((offsetof(StreamKernArgs, F) + sizeof(FrameArgs) + 7) & ~size_t(7)), "kernarg layout = struct layout");
 
+#ifndef RT_STREAM_WAVES
+#define RT_STREAM_WAVES 6           // waves per SIMD of the PCG / f16-node instantiation (see below)
+#endif
+constexpr int stream_waves(bool count, bool philox, bool h, bool tri) { return !tri ? 6 : (count || philox || !h) ? 5 : RT_STREAM_WAVES; }
 template <bool COUNT, bool PHILOX = false, bool H = false, bool TRI = true>
 // Waves per SIMD.  The kernel hides its memory and LDS latencies with resident waves.  Round 2 chose five (96 VGPRs; six = 80 VGPRs spilled
 // 26 dwords and lost: 14.18 against 14.70 Grays/s).  Round 4: compiled without structurizing uniform regions (__graft_entry__.py
@@ -61,10 +65,6 @@ template <bool COUNT, bool PHILOX = false, bool H = false, bool TRI = true>
 // entries per lane, so that six workgroups fit a CU — measure 18.3 against 17.1 Grays/s at five on the 100k-triangle workload, 16.2
 // against 15.1 on the million-triangle one (seven: 72 VGPRs + 5 dwords of scratch, 17.2; eight: 15.1).  The Philox instantiation spills
 // at 80 VGPRs (14 dwords: 13.1 against 15.8 Grays/s) and stays at five, like the f32-node and the counting instantiations.
-#ifndef RT_STREAM_WAVES
-#define RT_STREAM_WAVES 6
-#endif
-constexpr int stream_waves(bool count, bool philox, bool h, bool tri) { return !tri ? 6 : (count || philox || !h) ? 5 : RT_STREAM_WAVES; }
 // TRI = false: the instantiation for scenes without triangles (spheres only) — no traversal state, no burst; 76 / 86 VGPRs (PCG / Philox),
 // compiled for six waves per SIMD: 36.4 -> 39.3 (PCG; k_trace's sphere instantiation stays ahead at 41.7) and 32.6 -> 35.1 Grays/s (Philox)
 // on the sphere workload, eight waves (64 VGPRs, scratch): 37.6 / 29.7.
