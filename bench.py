@@ -370,9 +370,9 @@ def main():
         # against the 0.5 of the spec — most of it is half-rate (f16->f32 FMAs, min/max, compares, selects).  So the line reports
         # the VALU issue rate against the spec AND the share of the launch that the kernel's node steps and triangle tests would take at
         # the micro-benchmark's rates, the vector-memory issue share, and the HBM contract figures of SURVEY 8(d) (cache-served).
-        MIX = {"node_step_cycles_per_simd": 344.8, "valu_per_node_step": 84, "triangle_test_cycles_per_simd": 264.7, "valu_per_triangle_test": 65,
-               "waves_per_simd": 5, "source": "profiles/ubench_r03_node_mix.txt (tools/ubench/node_mix.hip: the product's node_step<true> / ray_triangle, "
-                                               "all lanes active, data in L1)"}
+        MIX = {"node_step_cycles_per_simd": 338.1, "valu_per_node_step": 88, "triangle_test_cycles_per_simd": 228.8, "valu_per_triangle_test": 54,
+               "waves_per_simd": 6, "source": "profiles/node4_ubench_r04.txt / ubench_r04_node_mix.txt (tools/ubench/node_mix.hip: the product's node_step<true> / "
+                                               "ray_triangle in lockstep, all lanes active, data in L1, six waves per SIMD; VALU per iteration = SQ_INSTS_VALU of that run)"}
         PROBES = {"plus_1_load_per_node_step": {"config3": -0.052, "config5": -0.052}, "plus_2_loads_per_node_step": {"config3": -0.133, "config5": -0.153},
                   "plus_13_valu_per_node_step": {"config3": -0.026, "config5": -0.028}, "plus_26_valu_per_node_step": {"config3": -0.048},
                   "plus_1_load_per_triangle_test": {"config3": -0.017, "config5": -0.014}, "plus_13_valu_per_triangle_test": {"config3": -0.013, "config5": -0.011},
