@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--decomposition", choices=["bands", "strips"], default="bands",
                     help="N>1: interleaved 8-row bands (balanced, default) or N contiguous strips")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--rng", choices=["pcg", "philox"], default="pcg", help="pcg = the reference's stream (parity mode, headline); philox = counter-based mode")
+    ap.add_argument("--rng", choices=["pcg", "philox"], default="pcg", help="pcg = the reference's stream (parity mode, headline); philox = the counter-based latency mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the (untimed) counting pass")
     ap.add_argument("--no-latency", action="store_true", help="skip the (untimed) single-frame latency measurements")

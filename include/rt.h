@@ -83,8 +83,11 @@ typedef struct rt_local_chunk {         /* 80 B: one MeshChunk of RayTracedMesh.
 
 enum {
     RT_RNG_PCG = 0,                     /* RayTracing.shader:193-204 — the reference's stream, the parity mode            */
-    RT_RNG_PHILOX = 1                   /* the perf mode: counter-based Philox4x32-10 (Salmon et al., SC'11).  NOT the reference's
-                                           stream: different noise, same expectation.  The reference chains one PCG state through every
+    RT_RNG_PHILOX = 1                   /* the LATENCY mode: counter-based Philox4x32-10 (Salmon et al., SC'11).  NOT the reference's
+                                           stream: different noise, same expectation.  A single frame finishes sooner in it (a pixel's samples
+                                           spread over 16 lanes: 16.3 against 18.3 ms on the headline workload, round 4); in launches of many
+                                           frames the PCG stream is the faster one (18.3 against 15.8 Grays/s: the generator costs more
+                                           instructions than the chain's hash and its kernel keeps five waves per SIMD instead of six).  The reference chains one PCG state through every
                                            sample and bounce of a pixel (RayTracing.shader:362,374-385), which forbids spreading a
                                            pixel's samples over lanes; here every draw is addressed by what it is for:
                                              key     = (pixelIndex, Frame)                     (frag :360-362)

@@ -23,6 +23,8 @@ def tree_shape(f32):
     level = [0]
     d = 0
     leaf_depth_sum, leaf_tris, max_leaf_depth = 0, 0, 0
+    leaf_sizes = [0, 0, 0, 0, 0]
+    kids_hist = [0, 0, 0, 0, 0]
     while level:
         nxt = []
         for i in level:
@@ -32,13 +34,16 @@ def tree_shape(f32):
                 if c & 0x80000000:
                     k = int(c & 3) + 1
                     leaf_depth_sum += (d + 1) * k; leaf_tris += k; max_leaf_depth = max(max_leaf_depth, d + 1)
+                    leaf_sizes[k] += 1
                 else:
                     nxt.append(int(c))
         level = nxt
         d += 1
     used = (refs != 0xFFFFFFFF).sum()
+    for row in (refs != 0xFFFFFFFF).sum(axis=1):
+        kids_hist[int(row)] += 1
     return {"levels": d, "mean_leaf_depth": round(leaf_depth_sum / max(leaf_tris, 1), 2), "max_leaf_depth": max_leaf_depth,
-            "children_per_node": round(float(used) / n, 3)}
+            "children_per_node": round(float(used) / n, 3), "leaves_by_triangle_count": leaf_sizes[1:], "nodes_by_child_count": kids_hist[1:]}
 
 
 def main():
