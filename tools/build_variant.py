@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B builds: tools/build_variant.py <name> [hipcc flags, e.g. -DRT_PROBE_VALU=13]  ->  ab_libs/librt_<name>.so (same ABI as the product
-library; selected at run time through RTX_LIB, see tools/ab_libs.sh).  Builds from the working tree with the product's flags."""
+library; selected at run time through RTX_LIB, see tools/ab_libs.sh).  Builds from the working tree with the product's flags;
+--drop=<flag> removes one of them first (an `-mllvm` option goes together with its `-mllvm`)."""
 import os
 import subprocess
 import sys
@@ -17,6 +18,10 @@ def build(name, extra):
     hipcc = g.shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs, _ = g.hip_sources()
     cflags = [f for f in g.HIPCC_FLAGS if f != "-shared"]
+    for d in [e[len("--drop="):] for e in extra if e.startswith("--drop=")]:
+        i = cflags.index(d)
+        del cflags[i - 1 if i and cflags[i - 1] == "-mllvm" else i:i + 1]
+    extra = [e for e in extra if not e.startswith("--drop=")]
     objs, procs = [], []
     for src in srcs:
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")

@@ -127,8 +127,22 @@ def count(lines, marked):
         prev_skip = m.group(1) if m else None
     regions = {r: {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0} for r in REGIONS}
     cold = {"valu": 0, "vmem": 0, "lds": 0, "salu": 0, "other": 0}
-    stack, problems, seen_loop = ["loop"], [], False
-    for b in blocks:
+    # The region a block starts in follows the CONTROL FLOW, not the layout (the compiler places a region's blocks wherever it likes: the
+    # leaf loop's accept path sits in front of the group fetch in one build and behind it in the next).  Successors: every branch target
+    # of the block plus the next block unless the block ends in s_branch / s_endpgm; the marker stack at a block's exit is handed to its
+    # successors, the first state to arrive stays (a disagreement is reported: a block shared by two regions).
+    index = {b["label"]: i for i, b in enumerate(blocks)}
+    succ = []
+    for i, b in enumerate(blocks):
+        code = [t for t in b["lines"] if not t.startswith((";", "."))]
+        out = [index[m.group(1)] for t in code for m in [re.match(r"^s_c?branch\w*\s+(\.LBB\d+_\d+)", t)] if m and m.group(1) in index]
+        last = code[-1].split()[0] if code else ""
+        if last not in ("s_branch", "s_endpgm", "s_setpc_b64") and i + 1 < len(blocks):
+            out.append(i + 1)
+        succ.append(out)
+
+    def walk(b, stack, tally):
+        stack = list(stack)
         for t in b["lines"]:
             m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
             if m and marked:
@@ -136,21 +150,43 @@ def count(lines, marked):
                     stack.append(m.group(2))
                 elif len(stack) > 1 and stack[-1] == m.group(2):
                     stack.pop()
-                else:
-                    problems.append(f"end {m.group(2)} while in {stack[-1]}")
-                    while len(stack) > 1 and stack[-1] != m.group(2):
+                elif m.group(2) in stack[1:]:
+                    if tally:
+                        problems.append(f"end {m.group(2)} while in {stack[-1]}")
+                    while stack[-1] != m.group(2):
                         stack.pop()
-                    if len(stack) > 1:
-                        stack.pop()
+                    stack.pop()
+                elif tally:
+                    problems.append(f"end {m.group(2)} outside it (in {stack[-1]})")
                 continue
-            if t.startswith((";", ".")):
+            if not tally or t.startswith((";", ".")):
                 continue
             k = kind(t.split()[0])
             r = b.get("option") or stack[-1]
             if r == "loop" and not b.get("in_loop"):            # straight-line code outside the persistent loop: before it or after it
-                r = "epilogue" if seen_loop else "prologue"
+                r = "epilogue" if b.get("after_loop") else "prologue"
             (cold if b.get("cold") else regions[r])[k] += 1
+        return tuple(stack)
+
+    problems, seen_loop = [], False
+    for b in blocks:
+        b["after_loop"] = seen_loop
         seen_loop = seen_loop or bool(b.get("in_loop"))
+    entry = {0: ("loop",)}
+    changed = True
+    while changed:
+        changed = False
+        for i, b in enumerate(blocks):
+            if i in entry and "exit" not in b:
+                b["exit"] = walk(b, entry[i], False)
+                for j in succ[i]:
+                    if j not in entry:
+                        entry[j] = b["exit"]; changed = True
+    for i, b in enumerate(blocks):
+        for j in succ[i]:
+            if i in entry and entry[j] != b["exit"] and not (b.get("cold") or blocks[j].get("cold")):
+                problems.append(f"{b['label']} leaves in {b['exit'][-1]}, {blocks[j]['label']} was entered in {entry[j][-1]}")
+        walk(b, entry.get(i, ("loop",)), True)
     return regions, cold, problems
 
 
