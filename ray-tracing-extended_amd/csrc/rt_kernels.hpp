@@ -124,9 +124,11 @@ constexpr int kNumCounters = 15 + kNumRegions;
 #ifdef RT_MARKERS
 #define RT_MARK(TEXT) asm volatile("; RTMARK " TEXT)
 #define RT_RARE_PATH() asm volatile("; RTRARE")      /* a block the benchmark configurations do not execute (option off, stack within its LDS part) */
+#define RT_RARE_PATH_EXPR() ({ asm volatile("; RTRARE"); 0; })                     /* the same inside a condition: (RT_RARE_PATH_EXPR(), test) */
 #else
 #define RT_MARK(TEXT) do { } while (0)
 #define RT_RARE_PATH() do { } while (0)
+#define RT_RARE_PATH_EXPR() 0
 #endif
 // (COUNT and cnt are the enclosing kernel's; the tick is one increment on the first active lane, in the counting build only)
 #define RT_REGION_BEGIN(NAME) do { RT_MARK("begin " #NAME); if (COUNT) { const unsigned long long rm_ = rtk::ballot_(true); \

@@ -93,10 +93,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
     auto pop = [&]() -> uint32_t {
         top -= 256u;
         if (gstk == nullptr) return slot(top);
+        RT_RARE_PATH();
         const uint32_t depth = top - stk0;
         uint32_t v = slot(stk0 + min(depth, capb - 256u));
         asm volatile("" : "+v"(v));          // keep this a ds_read: do not fold it into a pointer select with the load below
-        if (depth >= capb) v = gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride];
+        if (depth >= capb) { RT_RARE_PATH(); v = gstk[(size_t)((depth - capb) >> 8) * F.gstack_stride]; }
         return v;
     };
     // The work items of the wave's current group, decoded once per group (one lane per item) into LDS behind the stacks: per item
@@ -565,8 +566,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                     RT_REGION_BEGIN(nodeloop);
                     // (cur is an internal node only while the lane traverses: every exit from kModeTrav sets cur = kNone)
                     const int nAtNode = __popcll(ballot_((int)cur >= 0));
-                    if (nAtNode == 0) break;
-                    if (nAtNode < A.node_min && ballot2_(mode == kModeTrav, (int)cur < 0) != 0) break;   // few descenders: serve the leaves first
+                    if (nAtNode == 0) { RT_REGION_END(nodeloop); break; }
+                    if (nAtNode < A.node_min && ballot2_(mode == kModeTrav, (int)cur < 0) != 0) { RT_REGION_END(nodeloop); break; }   // few descenders: serve the leaves first
 #ifdef RT_DIAG_IDLE      // diagnostic build only: what the lanes that sit out a node step are waiting for (counters 3 / 4 re-used)
                     if (COUNT) {
                         if (mode == kModeTrav && (int)cur < 0) cnt.phase_lanes[3]++;          // holds a leaf
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                         float t0, t1, t2, t3;
                         uint32_t c0, c1, c2, c3;
                         node_step<H>(H ? S.nodes_h : S.nodes, cur, slab, best.t, F.full_sort != 0, t0, t1, t2, t3, c0, c1, c2, c3);
-                        if (gstk == nullptr || ballot_(top - stk0 + 768u > capb) == 0) {
+                        if (gstk == nullptr || ((void)RT_RARE_PATH_EXPR(), ballot_(top - stk0 + 768u > capb) == 0)) {
                             // branch-free push of the three farther children (far -> near); slots past the new top are garbage
                             slot(top) = c3; top = (t3 < INF) ? top + 256u : top;
                             slot(top) = c2; top = (t2 < INF) ? top + 256u : top;

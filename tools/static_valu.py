@@ -80,6 +80,9 @@ def kernels(text):
     return out
 
 
+DETAIL = None          # set to a dict to collect (region, block label) -> VALU instructions (debugging the attribution)
+
+
 def count(lines, marked):
     """per region: instructions of the blocks that run on real inputs.  The function body is cut into basic blocks (labels and the
     assembler's `; %bb.N:` comments); a block that holds an RTCOLD / RTRARE comment is cold, and so is everything after it up to the label
@@ -130,7 +133,7 @@ def count(lines, marked):
     # The region a block starts in follows the CONTROL FLOW, not the layout (the compiler places a region's blocks wherever it likes: the
     # leaf loop's accept path sits in front of the group fetch in one build and behind it in the next).  Successors: every branch target
     # of the block plus the next block unless the block ends in s_branch / s_endpgm; the marker stack at a block's exit is handed to its
-    # successors, the first state to arrive stays (a disagreement is reported: a block shared by two regions).
+    # successors.
     index = {b["label"]: i for i, b in enumerate(blocks)}
     succ = []
     for i, b in enumerate(blocks):
@@ -143,11 +146,15 @@ def count(lines, marked):
 
     def walk(b, stack, tally):
         stack = list(stack)
+        # a block that is entered only by falling through a conditional branch (`; %bb.N:`) and whose first marker opens a region is the
+        # body of the `if` that the region starts: the instructions the scheduler placed in front of the comment are the region's too
+        first = next((re.match(r"^; RTMARK (begin|end) (\w+)", t) for t in b["lines"] if t.startswith("; RTMARK")), None)
+        lead = first.group(2) if marked and first and first.group(1) == "begin" and b["label"].startswith("%bb") else None
         for t in b["lines"]:
             m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
             if m and marked:
                 if m.group(1) == "begin":
-                    stack.append(m.group(2))
+                    stack.append(m.group(2)); lead = None
                 elif len(stack) > 1 and stack[-1] == m.group(2):
                     stack.pop()
                 elif m.group(2) in stack[1:]:
@@ -162,30 +169,40 @@ def count(lines, marked):
             if not tally or t.startswith((";", ".")):
                 continue
             k = kind(t.split()[0])
-            r = b.get("option") or stack[-1]
+            r = b.get("option") or lead or stack[-1]
             if r == "loop" and not b.get("in_loop"):            # straight-line code outside the persistent loop: before it or after it
                 r = "epilogue" if b.get("after_loop") else "prologue"
             (cold if b.get("cold") else regions[r])[k] += 1
+            if k == "valu" and DETAIL is not None:
+                key = ("cold" if b.get("cold") else r, b["label"])
+                DETAIL[key] = DETAIL.get(key, 0) + 1
         return tuple(stack)
 
     problems, seen_loop = [], False
     for b in blocks:
         b["after_loop"] = seen_loop
         seen_loop = seen_loop or bool(b.get("in_loop"))
+    def common(a, c):
+        n = 0
+        while n < min(len(a), len(c)) and a[n] == c[n]:
+            n += 1
+        return a[:max(n, 1)]
+
+    # entry state of a block = the common prefix of its predecessors' exit states (a `break` leaves a region without passing its end
+    # comment: at the join the region is over), to a fixed point
     entry = {0: ("loop",)}
     changed = True
     while changed:
         changed = False
         for i, b in enumerate(blocks):
-            if i in entry and "exit" not in b:
-                b["exit"] = walk(b, entry[i], False)
-                for j in succ[i]:
-                    if j not in entry:
-                        entry[j] = b["exit"]; changed = True
+            if i not in entry:
+                continue
+            b["exit"] = walk(b, entry[i], False)
+            for j in succ[i]:
+                new = b["exit"] if j not in entry else common(entry[j], b["exit"])
+                if entry.get(j) != new:
+                    entry[j] = new; changed = True
     for i, b in enumerate(blocks):
-        for j in succ[i]:
-            if i in entry and entry[j] != b["exit"] and not (b.get("cold") or blocks[j].get("cold")):
-                problems.append(f"{b['label']} leaves in {b['exit'][-1]}, {blocks[j]['label']} was entered in {entry[j][-1]}")
         walk(b, entry.get(i, ("loop",)), True)
     return regions, cold, problems
 
