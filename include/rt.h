@@ -245,17 +245,22 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "tile_sync"       k_stream: 1 = a wave takes a whole 8x8 tile at a time, 0 = lanes refill pixel by pixel
  *   "stream_tile"     k_stream: frames interleaved in a wave, as log2: 0 = 8x8 pixels of one frame, 2 = 4x4 pixels x 4 frames of the
  *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)
- *   "device_bvh"      1 = build the BVH on the device (Morton order, PLOC clustering, breadth-first collapse to 4-wide nodes: 100k
- *                     triangles in 2.0 ms, 1M in 4.3 ms), 0 = the host's binned-SAH builder (50 ms / 600 ms, 5-10 % less traversal
- *                     work per ray), -1 (default) = device for rt_upload_local_meshes (meshes that move), host for world-space uploads
- *   "bvh_top"         device builder: once its bottom-up rounds have left at most this many clusters, the top of the tree is built by the
- *                     host's binned-SAH split search over the clusters' boxes (default 1024: work per ray 1.03x / 0.99x the host tree's on the
- *                     100k- / 1M-triangle workloads, against 1.10x / 1.05x with 0 = clustering up to the root)
+ *   "device_bvh"      1 = build the BVH on the device (Morton order, PLOC clustering, sweep-SAH treelet passes, breadth-first collapse to
+ *                     4-wide nodes: 100k triangles in 2.5 ms, 1M in 5.4 ms, traced within 1 % of / 2 % faster than the host tree), 0 = the
+ *                     host's binned-SAH builder (50 ms / 600 ms), -1 (default) = device for rt_upload_local_meshes (meshes that move), host
+ *                     for world-space uploads
+ *   "bvh_treelets"    device builder: number of sweep-SAH passes over the clustering's tree (default 6; 0 = none).  Pass k rebuilds, one wave
+ *                     each, every maximal subtree of <= 64 * 8^k triangles over its subtrees of <= 8^k triangles (pass 0: over the triangles
+ *                     themselves) with an exact sweep SAH — all three axes, every split position, large-box isolation — in the node slots the
+ *                     subtree already has (csrc/rt_bvh_gpu.hpp step 3c).  "bvh_treelet_ratio" (8), "bvh_treelet_first" (1) and
+ *                     "bvh_treelet_isolate" (1) tune the scale step, the first pass's item size and the isolation candidate
+ *   "bvh_radius"      device builder: PLOC search radius; n > 0: n in the first rounds, doubled once a quarter and again once a sixteenth of
+ *                     the clusters is left; n < 0: |n| in every round (default -16)
+ *   "bvh_top"         device builder: n > 0 = once its bottom-up rounds have left at most n clusters, the top of the tree is built by the host's
+ *                     binned-SAH split search over the clusters' boxes (round 3's way, default then 1024); 0 (default) = all on the device
  *   "peer_copies"     rt_multi: 1 = its device-to-device copies (scene fan-out, frame-end gather) go through hipMemcpyPeerAsync even between
  *                     contexts of one device — the branch a multi-GPU node takes, made runnable on a one-GPU box (default 0: peer API only
  *                     across devices)
- *   "bvh_radius"      device builder: PLOC search radius of the first rounds, 1..64 (default 8); it doubles once a quarter and again once
- *                     a sixteenth of the clusters is left; a negative value keeps |value| in every round
  *   "rebuild_percent" on-device geometry pipeline: after a refit, rebuild on the device once the summed internal box area exceeds
  *                     this percentage of its value right after the last build (default 200; 0 = never)
  *   "compact_nodes"   k_trace / k_stream: 1 = traverse the f16 form of the BVH nodes (5 loads per node visit, default), 0 = the

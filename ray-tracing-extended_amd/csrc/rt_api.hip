@@ -104,13 +104,17 @@ struct rt_ctx {
                                     // -1: device for the on-device geometry pipeline (meshes that move), host for world-space uploads
                                     // (a static scene is built once and traced for many frames: the SAH tree is traced 4-16 % faster,
                                     // the device build is 25-140x faster)
-    int opt_bvh_radius = 8;         // device builder: PLOC search radius of the first rounds; doubled once a quarter, again once a sixteenth of
-                                    // the clusters is left (negative = that radius in every round).  Work per ray against the host tree at
-                                    // 100k / 1M triangles: 8 -> 1.10 / 1.05, 12 -> 1.10 / 1.09, 16 -> 1.10 / 1.17, fixed 16 -> 1.07 / 1.13
+    int opt_bvh_radius = -16;       // device builder: PLOC search radius; positive: of the first rounds, doubled once a quarter and again once a
+                                    // sixteenth of the clusters is left; negative = that radius in every round (default: 16 throughout — with the
+                                    // treelet passes on top, profiles/sweep_devtree_r04.txt: wave-level node steps per ray 10.69 / 13.94 on the
+                                    // 100k / 1M workloads against 11.16 / 14.52 for 8 widening and 10.64 / 14.91 for the host's SAH tree)
     int opt_peer_copies = 0;        // 1: rt_multi's device-to-device copies take the peer API (hipMemcpyPeerAsync) even between contexts of ONE device
                                     // — the branch a multi-GPU node takes, runnable on a one-GPU box (tests)
-    int opt_bvh_top = 1024;         // device builder: once the bottom-up rounds have left at most this many clusters, the top of the tree is built by the
-                                    // host's binned-SAH split search over their boxes (a few hundred KB and about a millisecond; 0 = clustering to the root)
+    int opt_bvh_treelet_ratio = 8, opt_bvh_treelet_isolate = 1, opt_bvh_treelet_first = 1;      // (tuning of the passes: scale step, large-box isolation, first item size)
+    int opt_bvh_treelets = 6;       // device builder: sweep-SAH passes over the clustering's tree, one wave per treelet of <= 64 items (rt_bvh_gpu.hpp step 3c)
+    int opt_bvh_top = 0;            // device builder: > 0 = once the bottom-up rounds have left at most this many clusters, the top of the tree is built by
+                                    // the host's binned-SAH split search over their boxes (round 3's default 1024: a few hundred KB and about a
+                                    // millisecond of host time); 0 (default since round 4) = everything on the device: the treelet passes reach the root
     int opt_rebuild_percent = 200;  // device pipeline: rebuild instead of refit once the internal area exceeds this share of the build's
     int n_cu = 0;
     int opt_kernel = -1;            // -1: auto (k_trace or k_stream, measured per scene), 0: k_trace, 1: k_stream
@@ -255,7 +259,7 @@ int device_build(rt_ctx* c, uint32_t nt, float origin_magnitude)
     RT_HIP(c, hipEventRecord(c->evg0, c->stream));
     rtgb::Result res;
     RT_HIP(c, rtgb::build(c->stream, c->d_raw_tris.p, nt, origin_magnitude, c->opt_bvh_radius, c->bvh_ws, reinterpret_cast<rtbvh::Node4*>(c->d_nodes.p), c->d_order.p, res,
-                          (uint32_t)c->opt_bvh_top, bvh_tuning(c)));
+                          (uint32_t)c->opt_bvh_top, bvh_tuning(c), c->opt_bvh_treelets, c->opt_bvh_treelet_ratio, c->opt_bvh_treelet_isolate, c->opt_bvh_treelet_first));
     c->bvh.nodes.clear(); c->bvh.order.clear();
     c->n_nodes = res.n_nodes; c->bvh.levelStart = res.level_start; c->bvh.maxStack = res.max_stack; c->bvh.magnitude = res.magnitude;
     c->bvh.depth = res.levels;
@@ -1204,6 +1208,10 @@ int rt_set_option(rt_ctx* c, const char* name, int value)
     else if (!std::strcmp(name, "device_bvh")) { if (value < -1 || value > 1) return fail(c, -2, "device_bvh must be -1 (automatic), 0 or 1"); if (value != c->opt_device_bvh) c->scene_dirty = true; c->opt_device_bvh = value; }
     else if (!std::strcmp(name, "bvh_radius")) { if (value == 0 || value < -rtgb::kMaxRadius || value > rtgb::kMaxRadius) return fail(c, -2, "bvh_radius must be in [1,64] (negative: the same radius in every round)"); if (value != c->opt_bvh_radius) c->scene_dirty = true; c->opt_bvh_radius = value; }
     else if (!std::strcmp(name, "peer_copies")) { if (value != 0 && value != 1) return fail(c, -2, "peer_copies must be 0 or 1"); c->opt_peer_copies = value; }
+    else if (!std::strcmp(name, "bvh_treelet_ratio")) { if (value < 2 || value > 64) return fail(c, -2, "bvh_treelet_ratio must be in [2,64]"); if (value != c->opt_bvh_treelet_ratio) c->scene_dirty = true; c->opt_bvh_treelet_ratio = value; }
+    else if (!std::strcmp(name, "bvh_treelet_isolate")) { if (value < 0 || value > 1) return fail(c, -2, "bvh_treelet_isolate must be 0 or 1"); if (value != c->opt_bvh_treelet_isolate) c->scene_dirty = true; c->opt_bvh_treelet_isolate = value; }
+    else if (!std::strcmp(name, "bvh_treelet_first")) { if (value < 1 || value > 4096) return fail(c, -2, "bvh_treelet_first must be in [1,4096]"); if (value != c->opt_bvh_treelet_first) c->scene_dirty = true; c->opt_bvh_treelet_first = value; }
+    else if (!std::strcmp(name, "bvh_treelets")) { if (value < 0 || value > 16) return fail(c, -2, "bvh_treelets must be in [0,16] (passes)"); if (value != c->opt_bvh_treelets) c->scene_dirty = true; c->opt_bvh_treelets = value; }
     else if (!std::strcmp(name, "bvh_top")) { if (value < 0 || value > (1 << 20)) return fail(c, -2, "bvh_top must be in [0,1048576] (0 = the device's clustering builds the whole tree)"); if (value != c->opt_bvh_top) c->scene_dirty = true; c->opt_bvh_top = value; }
     else if (!std::strcmp(name, "rebuild_percent")) { if (value < 0 || value > 100000) return fail(c, -2, "rebuild_percent must be in [0,100000] (0 = never rebuild)"); c->opt_rebuild_percent = value; }
     else if (!std::strcmp(name, "stream_tile")) { if (value != 0 && value != 2 && value != 4) return fail(c, -2, "stream_tile must be 0 (8x8 pixels x 1 frame), 2 (4x4 x 4 frames) or 4 (2x2 x 16 frames)"); c->opt_stream_tile = value; }

@@ -10,6 +10,9 @@
 //                        union box has the smallest area; mutual pairs merge into a new binary node; the array is compacted
 //                        in order (block-local scan, scan of the block totals, gather).  Rounds run until one cluster is left;
 //                        the last <= 512 clusters finish inside a single workgroup without further launches.
+//   3c. treelets         (round 4) every maximal subtree of the clustering with <= 64 triangles is rebuilt by one wave with an exact
+//                        sweep SAH (all three axes, every split position) over its triangles, in the node slots it already has:
+//                        the clustering decides which triangles belong together, the split search how they are arranged
 //   4. collapse          breadth-first, one launch per level: a binary node becomes a 4-wide node by opening its larger internal
 //                        children; two sibling triangles form one leaf (the tracer's leaf size); children of one node are
 //                        allocated contiguously, levels are contiguous ranges (what the refit kernels need); child boxes get
@@ -30,7 +33,7 @@ namespace rtgb {
 
 constexpr int kMaxRadius = 64;          // PLOC search radius (neighbours looked at on each side): run-time, up to this
 constexpr int kPlocBlock = 512;         // clusters per workgroup and round
-constexpr int kCtrNodes = 0, kCtrNode4 = 1, kCtrOrder = 2, kCtrFrontier = 3, kCtrClusters = 4, kCtrBounds = 8;   // counter slots (uint32)
+constexpr int kCtrNodes = 0, kCtrNode4 = 1, kCtrOrder = 2, kCtrFrontier = 3, kCtrClusters = 4, kCtrBounds = 8, kCtrTreelets = 16;   // (kCtrTreelets + pass: up to 16 passes)   // counter slots (uint32)
 
 // monotone float <-> uint map for atomicMin / atomicMax on floats
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void k_leaf_boxes(const float* __restrict__ tr
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nt) return;
     const Box3 b = tri_box(tris + (size_t)ids[i] * 18);
-    bmin[i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
+    bmin[i] = make_float4(b.lo[0], b.lo[1], b.lo[2], __uint_as_float(1u));        // .w = triangles below the node (as an integer)
     bmax[i] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
     clusters[i] = i;
 }
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(kPlocBlock) void k_ploc_round(const uint32_t* __res
         if (mutual && e < j) {
             const uint32_t node = nt + atomicAdd(&ctr[kCtrNodes], 1u);
             const float4 amin = smin[e], amax = smax[e], cmin = smin[j], cmax = smax[j];
-            bmin[node] = make_float4(__builtin_fminf(amin.x, cmin.x), __builtin_fminf(amin.y, cmin.y), __builtin_fminf(amin.z, cmin.z), 0.f);
+            bmin[node] = make_float4(__builtin_fminf(amin.x, cmin.x), __builtin_fminf(amin.y, cmin.y), __builtin_fminf(amin.z, cmin.z),
+                                     __uint_as_float(__float_as_uint(amin.w) + __float_as_uint(cmin.w)));
             bmax[node] = make_float4(__builtin_fmaxf(amax.x, cmax.x), __builtin_fmaxf(amax.y, cmax.y), __builtin_fmaxf(amax.z, cmax.z), 0.f);
             child[node] = make_int2((int)sid[e], (int)sid[j]);
             keep = 1; value = node;
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(kPlocBlock) void k_ploc_tail(const uint32_t* __rest
             const bool mutual = j >= 0 && snn[j] == t;
             if (mutual && t < j) {
                 const uint32_t node = nt + atomicAdd(&ctr[kCtrNodes], 1u);
-                nmin = make_float4(__builtin_fminf(smin[t].x, smin[j].x), __builtin_fminf(smin[t].y, smin[j].y), __builtin_fminf(smin[t].z, smin[j].z), 0.f);
+                nmin = make_float4(__builtin_fminf(smin[t].x, smin[j].x), __builtin_fminf(smin[t].y, smin[j].y), __builtin_fminf(smin[t].z, smin[j].z),
+                                   __uint_as_float(__float_as_uint(smin[t].w) + __float_as_uint(smin[j].w)));
                 nmax = make_float4(__builtin_fmaxf(smax[t].x, smax[j].x), __builtin_fmaxf(smax[t].y, smax[j].y), __builtin_fmaxf(smax[t].z, smax[j].z), 0.f);
                 bmin[node] = nmin; bmax[node] = nmax;
                 child[node] = make_int2((int)sid[t], (int)sid[j]);
@@ -302,6 +307,225 @@ __global__ __launch_bounds__(256) void k_top_nodes(const int32_t* __restrict__ p
     bmax[base + k] = make_float4(b[3], b[4], b[5], 0.f);
 }
 
+// ---- 3c. treelets: sweep SAH over the bottom of the tree ------------------------------------------------------------------------
+// The clustering pairs nearest neighbours; which of a triangle's neighbours it ends up with depends on the order the rounds meet them,
+// and the bottom levels come out less regular than a split search's (3.3x as many single-triangle leaves on the headline scene, 12 %
+// more wave-level node steps).  So the bottom is rebuilt: a *treelet root* is a node of the clustering with at most kTreeletMax
+// triangles below it whose parent has more (or that was handed to the top as a cluster); one wave takes one root, collects its
+// triangles (one per lane) and the internal nodes of the subtree (their slots are reused), and builds the binary tree over them top
+// down: at every level, for every segment in parallel, the lanes are sorted along each axis (bitonic network on a key of segment |
+// centroid | lane), prefix and suffix boxes give the SAH cost area(L) * |L| + area(R) * |R| of EVERY split position (bvh.cpp's cost
+// function; no bins), the cheapest of the three axes wins.  The split between lanes i and i + 1 is made exactly once, so internal node
+// i of the treelet takes slot i of the collected ones (the root keeps its own: its parent's link stays valid).
+constexpr int kTreeletMax = 64;
+
+// roots: (1) the internal children with <= kTreeletMax triangles of a clustering node with more; (2) the candidates `extra`
+// (the clusters handed to the top builder / the clustering's own root) when they are internal and small enough
+__global__ __launch_bounds__(256) void k_treelet_roots(uint32_t nt, const float4* __restrict__ bmin, const int2* __restrict__ child,
+                                                       const uint32_t* __restrict__ extra, uint32_t n_extra, uint32_t* __restrict__ ctr,
+                                                       uint32_t* __restrict__ roots, uint32_t max_tris, uint32_t min_tris, int slot)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t made = ctr[kCtrNodes];
+    if (i < made) {
+        const uint32_t p = nt + i;
+        if (__float_as_uint(bmin[p].w) > max_tris) {
+            const int2 c = child[p];
+            const uint32_t kids[2] = { (uint32_t)c.x, (uint32_t)c.y };
+            for (int k = 0; k < 2; ++k)
+                if (kids[k] >= nt && kids[k] < nt + made && __float_as_uint(bmin[kids[k]].w) <= max_tris && __float_as_uint(bmin[kids[k]].w) >= min_tris)
+                    roots[atomicAdd(&ctr[kCtrTreelets + slot], 1u)] = kids[k];
+        }
+    }
+    if (i < n_extra) {
+        const uint32_t x = extra[i];
+        if (x >= nt && x < nt + made && __float_as_uint(bmin[x].w) <= max_tris && __float_as_uint(bmin[x].w) >= min_tris)
+            roots[atomicAdd(&ctr[kCtrTreelets + slot], 1u)] = x;
+    }
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// ascending bitonic sort of one key per lane over the wave
+__device__ __forceinline__ uint64_t wave_sort(uint64_t key, int lane)
+{
+    for (int k = 2; k <= 64; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t other = shfl_xor_u64(key, j);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            key = (lower == up) ? (other < key ? other : key) : (other > key ? other : key);
+        }
+    return key;
+}
+struct WBox { float lo[3], hi[3]; };
+__device__ __forceinline__ WBox wbox_shfl(const WBox& b, int src)
+{
+    WBox r;
+    for (int a = 0; a < 3; ++a) { r.lo[a] = __shfl(b.lo[a], src, 64); r.hi[a] = __shfl(b.hi[a], src, 64); }
+    return r;
+}
+__device__ __forceinline__ void wbox_grow(WBox& b, const WBox& o)
+{
+    for (int a = 0; a < 3; ++a) { b.lo[a] = __builtin_fminf(b.lo[a], o.lo[a]); b.hi[a] = __builtin_fmaxf(b.hi[a], o.hi[a]); }
+}
+__device__ __forceinline__ float wbox_area(const WBox& b)
+{
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+// inclusive scans of the boxes inside the segments [seg_lo, seg_hi): from the left and from the right
+__device__ __forceinline__ void wbox_scan(const WBox& b, int lane, int seg_lo, int seg_hi, WBox& pre, WBox& suf)
+{
+    pre = b; suf = b;
+    for (int off = 1; off < 64; off <<= 1) {
+        WBox o;
+        for (int a = 0; a < 3; ++a) { o.lo[a] = __shfl_up(pre.lo[a], off, 64); o.hi[a] = __shfl_up(pre.hi[a], off, 64); }
+        if (lane - off >= seg_lo) wbox_grow(pre, o);
+        for (int a = 0; a < 3; ++a) { o.lo[a] = __shfl_down(suf.lo[a], off, 64); o.hi[a] = __shfl_down(suf.hi[a], off, 64); }
+        if (lane + off < seg_hi) wbox_grow(suf, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_treelet_sah(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ ctr, uint32_t nt,
+                                                     float4* __restrict__ bmin, float4* __restrict__ bmax, int2* __restrict__ child, int pair_cost,
+                                                     uint32_t item_tris, int slot, int isolate)
+{
+    __shared__ uint32_t s_item[4][64], s_pool[4][64];
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    volatile uint32_t* items = s_item[wv]; volatile uint32_t* pool = s_pool[wv];
+    const uint32_t n_roots = ctr[kCtrTreelets + slot];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const float INF = __builtin_inff();
+    for (uint32_t r = blockIdx.x * 4u + (uint32_t)wv; r < n_roots; r += gridDim.x * 4u) {
+        const uint32_t root = roots[r];
+        // ---- the items below the root (one per lane, any order) — triangles, or in the later passes subtrees of at most item_tris
+        // triangles — and the internal nodes above them (pool[0] = the root), by opening the frontier until everything is an item or
+        // the wave is full (then the larger subtrees that are left count as items too)
+        uint32_t item = lane == 0 ? root : 0u;
+        uint32_t wt = lane == 0 ? __float_as_uint(bmin[root].w) : 0u;                 // triangles below the lane's item
+        int cnt = 1, n_int = 0;
+        for (;;) {
+            const bool want = lane < cnt && item >= nt && wt > item_tris;
+            const uint64_t wmask = __builtin_amdgcn_ballot_w64(want);
+            const int room = kTreeletMax - cnt;
+            if (wmask == 0ull || room <= 0) break;
+            const bool open = want && (int)__popcll(wmask & lt) < room;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(open);
+            const int rank = (int)__popcll(mask & lt), add = (int)__popcll(mask);
+            if (open) { const int2 c = child[item]; pool[n_int + rank] = item; item = (uint32_t)c.x; items[cnt + rank] = (uint32_t)c.y; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (lane >= cnt && lane < cnt + add) item = items[lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (open || (lane >= cnt && lane < cnt + add)) wt = item < nt ? 1u : __float_as_uint(bmin[item].w);
+            n_int += add; cnt += add;
+        }
+        const int n = cnt;
+        if (n < 3) continue;
+        WBox box;
+        if (lane < n) { const float4 mn = bmin[item], mx = bmax[item]; box.lo[0] = mn.x; box.lo[1] = mn.y; box.lo[2] = mn.z; box.hi[0] = mx.x; box.hi[1] = mx.y; box.hi[2] = mx.z; }
+        else for (int a = 0; a < 3; ++a) { box.lo[a] = INF; box.hi[a] = -INF; }
+        int seg_lo = lane < n ? 0 : lane, seg_hi = lane < n ? n : lane + 1;    // lanes without a triangle: segments of their own, never split
+        int par = -1, side = 0;                                                // the split (= slot) of the segment's parent; -1: the treelet's root
+        bool first = true;
+        for (;;) {
+            const bool active = seg_hi - seg_lo >= 2;
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            // ---- every split position of every segment, along each axis
+            float best = INF; int best_axis = 0, best_pos = seg_lo + ((seg_hi - seg_lo) >> 1) - 1;      // (nothing finite: the middle, along x)
+            int src_axis[3];                                    // the lane each position takes its item from, in the order along each axis
+            WBox whole; uint32_t wsum = 0u;                     // the segment's own box and triangle count (what its node stores)
+            float iso_cost = INF; int iso_pos = 0;
+            for (int axis = 0; axis < 3; ++axis) {
+                const float cen = 0.5f * box.lo[axis] + 0.5f * box.hi[axis];
+                const uint64_t key = wave_sort(((uint64_t)(uint32_t)seg_lo << 40) | ((uint64_t)f2ord(cen) << 8) | (uint64_t)(uint32_t)lane, lane);
+                const int src = (int)(key & 0xFFull);
+                src_axis[axis] = src;
+                const WBox sb = wbox_shfl(box, src);
+                WBox pre, suf;
+                wbox_scan(sb, lane, seg_lo, seg_hi, pre, suf);
+                const WBox right = wbox_shfl(suf, min(lane + 1, 63));
+                // triangles on the left of every position (the order along this axis): inclusive scan of the weights inside the segment
+                const uint32_t w0 = (uint32_t)__shfl((int)wt, src, 64);
+                uint32_t wl = w0;
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)wl, off, 64); if (lane - off >= seg_lo) wl += o; }
+                const uint32_t wall = (uint32_t)__shfl((int)wl, seg_hi - 1, 64);
+                if (axis == 0) {
+                    whole = wbox_shfl(pre, seg_hi - 1); wsum = wall;
+                    // large-box isolation (bvh.cpp's extra candidate): a sweep over centroids can never separate an item whose box spans
+                    // the segment (a floor triangle among a thousand small ones) from the rest — it would sink to the bottom and inflate
+                    // every box on its way.  Candidate: the item of largest area alone against everything else.
+                    if (isolate) {
+                        float ma = wbox_area(sb); ma = (lane < n && ma == ma) ? ma : -1.f;
+                        int mp = lane;
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const float oa = __shfl_up(ma, off, 64); const int op = __shfl_up(mp, off, 64);
+                            if (lane - off >= seg_lo && oa > ma) { ma = oa; mp = op; }
+                        }
+                        ma = __shfl(ma, seg_hi - 1, 64); mp = __shfl(mp, seg_hi - 1, 64);
+                        WBox rest = wbox_shfl(pre, max(mp - 1, 0));
+                        const WBox after = wbox_shfl(suf, min(mp + 1, 63));
+                        if (mp == seg_lo) rest = after; else if (mp + 1 < seg_hi) wbox_grow(rest, after);
+                        const uint32_t wb = (uint32_t)__shfl((int)w0, mp, 64);
+                        if (active && seg_hi - seg_lo > 2 && ma > 0.25f * wbox_area(whole)) {
+                            const uint32_t nr = wall - wb;
+                            const float c = pair_cost ? ma * (float)((wb + 1u) >> 1) + wbox_area(rest) * (float)((nr + 1u) >> 1) : ma * (float)wb + wbox_area(rest) * (float)nr;
+                            iso_cost = (c == c) ? c : INF; iso_pos = mp;
+                        }
+                    }
+                }
+                float cost = INF;
+                if (active && lane < seg_hi - 1) {
+                    const uint32_t nl = wl, nr = wall - wl;
+                    // pair_cost: a side's cost in LEAVES (two sibling triangles share one, step 4): odd / odd splits of an even count pay for it
+                    cost = pair_cost ? wbox_area(pre) * (float)((nl + 1u) >> 1) + wbox_area(right) * (float)((nr + 1u) >> 1)
+                                     : wbox_area(pre) * (float)nl + wbox_area(right) * (float)nr;
+                    cost = (cost == cost) ? cost : INF;
+                }
+                // the segment's cheapest position (ties: the leftmost): min-scan from the left, read at the segment's last lane
+                float mc = cost; int mp = lane;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float oc = __shfl_up(mc, off, 64); const int op = __shfl_up(mp, off, 64);
+                    if (lane - off >= seg_lo && oc <= mc) { mc = oc; mp = op; }
+                }
+                mc = __shfl(mc, seg_hi - 1, 64); mp = __shfl(mp, seg_hi - 1, 64);
+                if (mc < best) { best = mc; best_axis = axis; best_pos = mp; }
+            }
+            // ---- the lanes of every segment in the order of its best axis; an isolated item: the x order with that item moved to the end
+            {
+                int src = best_axis == 0 ? src_axis[0] : best_axis == 1 ? src_axis[1] : src_axis[2];
+                if (iso_cost < best) {
+                    const int next = __shfl(src_axis[0], min(lane + 1, 63), 64), big = __shfl(src_axis[0], iso_pos, 64);
+                    src = lane < iso_pos ? src_axis[0] : lane < seg_hi - 1 ? next : big;
+                    best_pos = seg_hi - 2;
+                }
+                box = wbox_shfl(box, src);
+                item = (uint32_t)__shfl((int)item, src, 64);
+                wt = (uint32_t)__shfl((int)wt, src, 64);
+            }
+            if (first) {                                    // the root keeps its slot: it becomes the slot of the root's split
+                if (lane == 0) { const uint32_t t = pool[best_pos]; pool[best_pos] = pool[0]; pool[0] = t; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                first = false;
+            }
+            if (active) {
+                const uint32_t node = pool[best_pos];
+                if (lane == seg_lo) {
+                    bmin[node] = make_float4(whole.lo[0], whole.lo[1], whole.lo[2], __uint_as_float(wsum));
+                    bmax[node] = make_float4(whole.hi[0], whole.hi[1], whole.hi[2], 0.f);
+                    if (par >= 0) reinterpret_cast<int*>(&child[pool[par]])[side] = (int)node;
+                }
+                par = best_pos;
+                if (lane <= best_pos) { seg_hi = best_pos + 1; side = 0; } else { seg_lo = best_pos + 1; side = 1; }
+                if (seg_hi - seg_lo == 1) reinterpret_cast<int*>(&child[pool[par]])[side] = (int)item;      // one item: final
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();        // (the next root reuses the wave's LDS)
+    }
+}
+
 // ---- 4. collapse to 4-wide nodes, one level per launch --------------------------------------------------------------------
 __device__ __forceinline__ bool leaf_unit(uint32_t x, uint32_t nt, const int2* __restrict__ child)
 {
@@ -310,10 +534,14 @@ __device__ __forceinline__ bool leaf_unit(uint32_t x, uint32_t nt, const int2* _
     return (uint32_t)c.x < nt && (uint32_t)c.y < nt;           // two sibling triangles: one leaf
 }
 
+// tin / tout (optional): the first position in `order` of the triangles below each frontier entry — with the triangle counts of the
+// binary nodes (bmin.w) the records of a subtree land next to each other, in depth-first order (what the host builder's index array
+// gives); without them the leaves take positions as the levels reach them.
 __global__ __launch_bounds__(256) void k_collapse_level(const uint2* __restrict__ fin, uint32_t nin, uint2* __restrict__ fout, uint32_t nt,
                                                         const float4* __restrict__ bmin, const float4* __restrict__ bmax, const int2* __restrict__ child,
                                                         const uint32_t* __restrict__ sorted_ids, rtbvh::Node4* __restrict__ nodes,
-                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ ctr, float G)
+                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ ctr, float G,
+                                                        const uint32_t* __restrict__ tin, uint32_t* __restrict__ tout)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nin) return;
@@ -341,7 +569,7 @@ __global__ __launch_bounds__(256) void k_collapse_level(const uint2* __restrict_
     }
     const uint32_t nbase = n_int ? atomicAdd(&ctr[kCtrNode4], n_int) : 0u;
     const uint32_t fbase = n_int ? atomicAdd(&ctr[kCtrFrontier], n_int) : 0u;
-    uint32_t obase = n_tri ? atomicAdd(&ctr[kCtrOrder], n_tri) : 0u;
+    uint32_t obase = tin ? tin[i] : n_tri ? atomicAdd(&ctr[kCtrOrder], n_tri) : 0u;
     rtbvh::Node4 N;
     uint32_t ri = 0;
     const float INF = __builtin_inff();
@@ -369,6 +597,7 @@ __global__ __launch_bounds__(256) void k_collapse_level(const uint2* __restrict_
         } else {
             N.child[k] = nbase + ri;
             fout[fbase + ri] = make_uint2(x, nbase + ri);
+            if (tin) { tout[fbase + ri] = obase; obase += __float_as_uint(mn.w); }
             ++ri;
         }
     }
@@ -427,13 +656,14 @@ struct Workspace {
     Buf<float4> bmin, bmax;
     Buf<int2> child;
     Buf<uint2> f0, f1;
+    Buf<uint32_t> t0, t1;                               // collapse: first triangle position of each frontier entry
     Buf<int> need;
     Buf<float> area;
     void release()
     {
         keys0.release(); keys1.release(); ids0.release(); ids1.release(); c0.release(); c1.release(); tmp.release(); block_count.release();
         block_offset.release(); ctr.release(); sort_tmp.release(); bmin.release(); bmax.release(); child.release(); f0.release(); f1.release();
-        need.release(); area.release(); top_boxes.release(); top_pairs.release();
+        need.release(); area.release(); top_boxes.release(); top_pairs.release(); t0.release(); t1.release();
     }
 };
 
@@ -450,8 +680,9 @@ struct Result {
 // origin_magnitude: largest |coordinate| of a ray origin outside the triangles (camera, spheres).
 // top_clusters: once the bottom-up rounds have left at most this many clusters, the rest of the tree — its top — is built by the
 // host's binned-SAH split search over the clusters' boxes (0: the rounds run down to 512 clusters and one workgroup finishes).
+// treelets: number of sweep-SAH passes over the clustering's tree (step 3c; 0 = none).
 inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, float origin_magnitude, int radius, Workspace& w,
-                        rtbvh::Node4* nodes, uint32_t* order, Result& out, uint32_t top_clusters, const rtbvh::Tuning& tuning)
+                        rtbvh::Node4* nodes, uint32_t* order, Result& out, uint32_t top_clusters, const rtbvh::Tuning& tuning, int treelets = 6, int treelet_ratio = 8, int treelet_isolate = 1, int treelet_first = 1)
 {
     const bool widen = radius > 0;              // a negative radius = that radius in every round (A/B of the schedule)
     radius = std::max(1, std::min(radius < 0 ? -radius : radius, kMaxRadius));
@@ -462,7 +693,7 @@ inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, floa
     RTGB_HIP(w.c0.ensure(nt)); RTGB_HIP(w.c1.ensure(nt)); RTGB_HIP(w.tmp.ensure((size_t)nb0 * kPlocBlock));
     RTGB_HIP(w.block_count.ensure(nb0)); RTGB_HIP(w.block_offset.ensure(nb0)); RTGB_HIP(w.ctr.ensure(32));
     RTGB_HIP(w.bmin.ensure(2 * (size_t)nt)); RTGB_HIP(w.bmax.ensure(2 * (size_t)nt)); RTGB_HIP(w.child.ensure(2 * (size_t)nt));
-    RTGB_HIP(w.f0.ensure(nt)); RTGB_HIP(w.f1.ensure(nt)); RTGB_HIP(w.need.ensure((size_t)nt + 1)); RTGB_HIP(w.area.ensure(1));
+    RTGB_HIP(w.f0.ensure(nt)); RTGB_HIP(w.f1.ensure(nt)); RTGB_HIP(w.t0.ensure(nt)); RTGB_HIP(w.t1.ensure(nt)); RTGB_HIP(w.need.ensure((size_t)nt + 1)); RTGB_HIP(w.area.ensure(1));
 
     uint32_t h_ctr[32] = {};
     for (int a = 0; a < 3; ++a) { h_ctr[kCtrBounds + a] = 0xFFFFFFFFu; h_ctr[kCtrBounds + 3 + a] = 0u; }
@@ -534,21 +765,44 @@ inline hipError_t build(hipStream_t stream, const float* tris, uint32_t nt, floa
     const float G = std::max(origin_magnitude, ord2f(h_bounds[6]));
     out.magnitude = G;
 
+    // ---- the bottom of the tree again, by the sweep SAH (the clustering's nodes only: the top's clusters are the candidates beside them)
+    if (treelets && nt >= 3) {
+        const bool has_top = top_clusters > 0 && m >= 2;
+        const uint32_t n_extra = has_top ? m : 1u;
+        const uint32_t* extra = has_top ? cin : w.ctr.p + kCtrClusters + 1;
+        // pass k: items = subtrees of <= ratio^k triangles (as the pass before left them), roots = maximal subtrees of <= 64 * ratio^k:
+        // every pass regroups what the one below it built, across the boundaries the clustering had drawn at that scale; with enough
+        // passes (6 for a million triangles at ratio 8) the last one has the whole tree as its one treelet
+        uint32_t item_tris = (uint32_t)treelet_first;
+        for (int pass = 0; pass < treelets && pass < 16 && (pass == 0 || item_tris < nt); ++pass, item_tris *= (uint32_t)treelet_ratio) {
+            const uint32_t max_tris = (uint32_t)kTreeletMax * item_tris;
+            hipLaunchKernelGGL(k_treelet_roots, dim3((std::max(nt, n_extra) + 255) / 256), dim3(256), 0, stream, nt, w.bmin.p, w.child.p, extra, n_extra, w.ctr.p, w.tmp.p,
+                               max_tris, 2u * item_tris + 1u, pass);
+            const uint32_t blocks = std::min<uint32_t>(2048u, nt / (32u * item_tris) + 1u);
+            hipLaunchKernelGGL(k_treelet_sah, dim3(blocks), dim3(256), 0, stream, w.tmp.p, w.ctr.p, nt, w.bmin.p, w.bmax.p, w.child.p,
+                               item_tris == 1 ? 1 : 0, item_tris, pass, treelet_isolate);
+        }
+    }
+
     // ---- collapse, level by level
     const uint2 first = make_uint2(root, 0u);
     RTGB_HIP(hipMemcpyAsync(w.f0.p, &first, sizeof first, hipMemcpyHostToDevice, stream));
     uint2* fin = w.f0.p; uint2* fout = w.f1.p;
+    // every binary node carries its triangle count unless the host built the top (its nodes do not): depth-first triangle order then
+    const bool dfs_order = !(top_clusters > 0 && m >= 2);
+    uint32_t* tin = dfs_order ? w.t0.p : nullptr; uint32_t* tout = dfs_order ? w.t1.p : nullptr;
+    if (dfs_order) RTGB_HIP(hipMemsetAsync(w.t0.p, 0, sizeof(uint32_t), stream));
     uint32_t nin = 1, total = 1;
     out.level_start.push_back(0);
     while (nin > 0) {
         RTGB_HIP(hipMemsetAsync(w.ctr.p + kCtrFrontier, 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_collapse_level, dim3((nin + 255) / 256), dim3(256), 0, stream, fin, nin, fout, nt, w.bmin.p, w.bmax.p, w.child.p,
-                           w.ids1.p, nodes, order, w.ctr.p, G);
+                           w.ids1.p, nodes, order, w.ctr.p, G, tin, tout);
         uint32_t nout = 0;
         RTGB_HIP(hipMemcpyAsync(&nout, w.ctr.p + kCtrFrontier, sizeof nout, hipMemcpyDeviceToHost, stream));
         RTGB_HIP(hipStreamSynchronize(stream));
         out.level_start.push_back(total);
-        total += nout; nin = nout; std::swap(fin, fout); ++out.levels;
+        total += nout; nin = nout; std::swap(fin, fout); std::swap(tin, tout); ++out.levels;
     }
     out.n_nodes = total;
     if (out.level_start.back() != total) out.level_start.push_back(total);

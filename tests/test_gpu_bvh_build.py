@@ -27,7 +27,7 @@ def _render_with(tracer, b, builder, frames=2, counting=False, want_bvh=False, *
         return tracer.read_accum(), tracer.stats()
     finally:
         tracer.set_option("device_bvh", -1)
-        tracer.set_option("bvh_radius", 8)
+        tracer.set_option("bvh_radius", -16)
 
 
 @pytest.mark.parametrize("radius", [1, 8, -16, 64])
@@ -79,9 +79,10 @@ def test_device_builder_small_and_awkward_triangle_counts(rtx, oracle, tracer, n
 
 
 def test_device_builder_meets_the_build_time_and_quality_bars(rtx, tracer):
-    """100,440 and 1,004,364 triangles: build time (HIP events around sort + clustering + the host-built top of the tree + collapse +
-    triangle records + f16 nodes) under 6 ms, traversal work per ray (node visits + triangle tests, counting build, 480x270 x 2 rays)
-    within 5 % of the host's binned-SAH tree, same image.  The same with the clustering alone (bvh_top = 0): within 15 %."""
+    """100,440 and 1,004,364 triangles: build time (HIP events around sort + clustering + treelet passes + collapse + triangle records
+    + f16 nodes) under 6.5 ms, traversal work per ray (node visits + triangle tests, counting build, 480x270 x 2 rays) within 3 % of the
+    host's binned-SAH tree, same image.  Round 3's builder (clustering + a host-built top over 1024 clusters, no treelet passes): within
+    5 %; the clustering alone: within 15 %."""
     for gen, tri_count in ((rtx.scenes.config3, 100440), (rtx.scenes.config5, 1004364)):
         m = gen(480, 270)
         m.numRaysPerPixel = 2
@@ -93,16 +94,37 @@ def test_device_builder_meets_the_build_time_and_quality_bars(rtx, tracer):
         assert_bitwise(dev_img, host_img, f"{tri_count} triangles: device tree vs host tree")
         work_h = (sh["nodeVisits"] + sh["triTests"]) / sh["rays"]
         work_d = (sd["nodeVisits"] + sd["triTests"]) / sd["rays"]
-        assert sd["bvhBuiltOnDevice"] == 1 and sd["lastBvhBuildMs"] < 6.0, sd["lastBvhBuildMs"]
-        assert work_d <= 1.05 * work_h, (tri_count, work_d, work_h)
+        assert sd["bvhBuiltOnDevice"] == 1 and sd["lastBvhBuildMs"] < 6.5, sd["lastBvhBuildMs"]
+        assert work_d <= 1.03 * work_h, (tri_count, work_d, work_h)
         assert sd["bvhMaxStack"] < 64
-        tracer.set_option("bvh_top", 0)
+        for opts, bar in (({"bvh_top": 1024, "bvh_treelets": 0, "bvh_radius": 8}, 1.05), ({"bvh_top": 0, "bvh_treelets": 0, "bvh_radius": 8}, 1.15)):
+            for k, v in opts.items():
+                tracer.set_option(k, v)
+            try:
+                img, sp = _render_with(tracer, b, 1, frames=1, counting=True, bvh_radius=opts["bvh_radius"])
+            finally:
+                tracer.set_option("bvh_top", 0); tracer.set_option("bvh_treelets", 6)
+            assert_bitwise(img, host_img, f"{tri_count} triangles: {opts} vs host tree")
+            assert (sp["nodeVisits"] + sp["triTests"]) / sp["rays"] <= bar * work_h, opts
+
+
+@pytest.mark.parametrize("passes,ratio,first,isolate", [(1, 8, 1, 1), (2, 4, 1, 0), (3, 8, 2, 1), (16, 2, 1, 1), (6, 64, 1, 1)])
+def test_treelet_passes_keep_the_image(rtx, oracle, tracer, passes, ratio, first, isolate):
+    """The sweep-SAH treelet passes in unusual settings (one pass, tiny / huge scale steps, items of two triangles first, no
+    isolation candidate), with and without the host-built top: the tree changes, the image does not."""
+    b = list(rtx.scenes.mesh_test_scene(96, 64).build_buffers())
+    want, _, cnt = oracle.render(*b, 0, 2)
+    for top in (0, 7):
+        for k, v in (("bvh_treelets", passes), ("bvh_treelet_ratio", ratio), ("bvh_treelet_first", first), ("bvh_treelet_isolate", isolate), ("bvh_top", top)):
+            tracer.set_option(k, v)
         try:
-            ploc_img, sp = _render_with(tracer, b, 1, frames=1, counting=True)
+            got, st = _render_with(tracer, b, 1)
         finally:
-            tracer.set_option("bvh_top", 1024)
-        assert_bitwise(ploc_img, host_img, f"{tri_count} triangles: clustering-only tree vs host tree")
-        assert (sp["nodeVisits"] + sp["triTests"]) / sp["rays"] <= 1.15 * work_h
+            for k, v in (("bvh_treelets", 6), ("bvh_treelet_ratio", 8), ("bvh_treelet_first", 1), ("bvh_treelet_isolate", 1), ("bvh_top", 0)):
+                tracer.set_option(k, v)
+        assert st["bvhBuiltOnDevice"] == 1
+        assert_bitwise(got, want, f"treelets {passes} x{ratio} first {first} iso {isolate} top {top}")
+        assert st["rays"] == cnt["rays"]
 
 
 def test_refit_that_inflates_the_tree_triggers_a_device_rebuild(rtx, tracer):

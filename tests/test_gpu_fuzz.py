@@ -135,9 +135,9 @@ def test_random_scene_matches_the_oracle(rtx, oracle, tracer, seed):
              "max_leaf": int(rng.choice([1, 2, 4])), "full_sort": int(rng.integers(0, 2)), "frame_batch": int(rng.choice([0, 1])),
              "bvh_reinsert": int(rng.choice([0, 0, 2])),
              "stream_tile": int(rng.choice([0, 2, 4])), "compact_nodes": int(rng.choice([0, 1, 1])), "tile_lpt": int(rng.choice([0, 1, 1])),
-             "device_bvh": int(rng.choice([0, 1])), "bvh_collapse": int(rng.choice([0, 1, 2])), "bvh_radius": int(rng.choice([2, 8, -16, 40])), "bvh_top": int(rng.choice([0, 2, 600, 1024]))}
+             "device_bvh": int(rng.choice([0, 1])), "bvh_collapse": int(rng.choice([0, 1, 2])), "bvh_radius": int(rng.choice([2, 8, -16, 40])), "bvh_top": int(rng.choice([0, 2, 600, 1024])), "bvh_treelets": int(rng.choice([0, 1, 3, 6]))}
     defaults = {"stream_stack": 0, "node_min": 10, "tiles_per_fetch": 16, "max_leaf": 2, "full_sort": 0, "frame_batch": 0,
-                "bvh_reinsert": 0, "fetch_guide": 4, "stream_tile": 4, "compact_nodes": 1, "tile_lpt": 1, "device_bvh": -1, "bvh_collapse": 0, "bvh_radius": 8, "bvh_top": 1024}
+                "bvh_reinsert": 0, "fetch_guide": 4, "stream_tile": 4, "compact_nodes": 1, "tile_lpt": 1, "device_bvh": -1, "bvh_collapse": 0, "bvh_radius": -16, "bvh_top": 0, "bvh_treelets": 6}
     nf = int(rng.choice([2, 2, 4, 5]))                  # 4 and 5: whole frame groups of 4 (+ a remainder) when stream_tile allows
     for k, v in knobs.items():
         tracer.set_option(k, v)
