@@ -247,8 +247,9 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)
  *   "device_bvh"      1 = build the BVH on the device (Morton order, PLOC clustering, sweep-SAH treelet passes, breadth-first collapse to
  *                     4-wide nodes: 100k triangles in 2.5 ms, 1M in 5.4 ms, traced within 1 % of / 2 % faster than the host tree), 0 = the
- *                     host's binned-SAH builder (50 ms / 600 ms), -1 (default) = device for rt_upload_local_meshes (meshes that move), host
- *                     for world-space uploads
+ *                     host's binned-SAH builder (50 ms / 600 ms), -1 (default) = device for rt_upload_local_meshes (meshes that move) and
+ *                     for a world-space scene that is uploaded again within 16 traced frames of its last build (the reference's way of
+ *                     animating: everything re-sent every frame), host for the first build of a world-space scene
  *   "bvh_treelets"    device builder: number of sweep-SAH passes over the clustering's tree (default 6; 0 = none).  Pass k rebuilds, one wave
  *                     each, every maximal subtree of <= 64 * 8^k triangles over its subtrees of <= 8^k triangles (pass 0: over the triangles
  *                     themselves) with an exact sweep SAH — all three axes, every split position, large-box isolation — in the node slots the

@@ -71,6 +71,7 @@ struct rt_ctx {
     float sphere_mag = 0.f;                             // largest |coordinate| of a sphere surface point of that scene
     // on-device geometry pipeline (rt_upload_local_meshes / rt_set_mesh_transforms)
     bool geom_local = false, xf_dirty = false;
+    uint64_t frames_traced = 0, frames_at_world_build = ~0ull;     // device_bvh = -1: a world-space scene that changes again soon is one that moves
     std::vector<rt_triangle>       h_local_tris;
     std::vector<rt_local_chunk>    h_lchunks;
     std::vector<rt_mesh_transform> h_xf;
@@ -335,7 +336,12 @@ int build_scene(rt_ctx* c)
     // 2e-6 * G), so a camera that drifts away from the geometry widens the padding (repad_boxes) once per doubling, not per frame
     const float origin_mag = 2.0f * std::max(camera_magnitude(c->params), sphere_magnitude(c));
     c->stats.bvhBuiltOnDevice = 0;
-    if (c->opt_device_bvh == 1 && nt > 0) {
+    // device_bvh = -1: the first build of a world-space scene is the host's (a static scene is built once); a scene that is uploaded
+    // again within 16 traced frames of its last build is being animated the reference's way — the whole scene re-sent every frame,
+    // RayTracedMesh.cs:36-84 — and a 50-600 ms host build per frame would dwarf the trace: those builds go to the device (2.5-5.4 ms)
+    const bool moving = c->opt_device_bvh == -1 && c->frames_at_world_build != ~0ull && c->frames_traced - c->frames_at_world_build <= 16;
+    c->frames_at_world_build = c->frames_traced;
+    if ((c->opt_device_bvh == 1 || moving) && nt > 0) {
         // the device builder takes every uploaded triangle; one that belongs to no chunk gets NaN records (k_relayout) and can never be hit
         RT_UP(c->d_tri_chunk, chunk_of, uint32_t) RT_UP(c->d_tri_rank, visit_rank, uint32_t)
         { int r = device_build(c, (uint32_t)nt, origin_mag); if (r) return r; }
@@ -626,6 +632,7 @@ template <class Fn> const void* dispatch3(bool a, bool b, bool c3, Fn f)
 // One kernel choice for all n_frames (kernel: 0 k_trace, 1 k_stream).
 int launch_frames_k(rt_ctx* c, int first_frame, int n_frames, Variant var, int kernel)
 {
+    c->frames_traced += (uint64_t)std::max(n_frames, 0);
     if (!c) return -1;
     if (!c->have_params) return fail(c, -2, "rt_set_params has not been called");
     if (n_frames < 0) return fail(c, -2, "n_frames < 0");

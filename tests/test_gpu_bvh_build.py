@@ -127,6 +127,34 @@ def test_treelet_passes_keep_the_image(rtx, oracle, tracer, passes, ratio, first
         assert st["rays"] == cnt["rays"]
 
 
+def test_world_space_scene_that_keeps_changing_is_rebuilt_on_the_device(rtx, oracle):
+    """device_bvh = -1 (default): the first build of a world-space scene is the host's; the same scene uploaded again — moved, the
+    reference's way of animating (RayTracedMesh.cs:36-84) — within 16 traced frames is built on the device; left alone for longer,
+    the next change is a host build again.  Images == oracle throughout."""
+    tr = rtx.Tracer(0)
+    try:
+        params, spheres, tris, infos = rtx.scenes.mesh_test_scene(96, 64).build_buffers()
+        tr.set_params(params); tr.set_rows(0, int(params["height"]))
+        built = []
+        for step, frames in enumerate((2, 2, 20, 2)):
+            moved = tris.copy()
+            for k in ("posA", "posB", "posC"):
+                moved[k] = tris[k] + np.float32([0.0, 0.01 * step, 0.0])
+            mi = infos.copy(); mi["boundsMin"] = infos["boundsMin"] + np.float32([0, 0.01 * step, 0]); mi["boundsMax"] = infos["boundsMax"] + np.float32([0, 0.01 * step, 0])
+            tr.upload(spheres=spheres, triangles=moved, meshinfo=mi)
+            tr.reset_accum()
+            tr.render(0, frames)
+            st = tr.stats()
+            built.append(int(st["bvhBuiltOnDevice"]))
+            if frames == 2:
+                want, _, cnt = oracle.render(params, spheres, moved, mi, 0, 2)
+                assert_bitwise(tr.read_accum(), want, f"step {step}")
+                assert st["rays"] == cnt["rays"]
+        assert built == [0, 1, 1, 0], built
+    finally:
+        tr.close()
+
+
 def test_refit_that_inflates_the_tree_triggers_a_device_rebuild(rtx, tracer):
     """On-device geometry pipeline: small moves refit (topology kept); spreading the meshes far apart inflates the refitted boxes
     past rebuild_percent and the tree is rebuilt on the device — the image equals a fresh host-transformed upload either way."""
