@@ -230,6 +230,10 @@ def main():
         params = params.copy()
         params["rngMode"] = 1
         buffers = (params, spheres, tris, infos)
+    if os.environ.get("RTX_BENCH_BRUTE") == "1":           # diagnostic only (what the literal chunk-box filter costs): NOT the benchmark's semantics
+        params = params.copy()
+        params["intersectMode"] = 1
+        buffers = (params, spheres, tris, infos)
     W, H = int(params["width"]), int(params["height"])
     banded = (world > 1 or force_dist) and args.decomposition == "bands"
     sim = args.as_rank_of if world == 1 and args.as_rank_of > 1 and not force_dist else 0
@@ -524,7 +528,7 @@ def main():
         "ms_per_step": round(wall / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{names[args.config]}, {W}x{H}, {int(params['numRaysPerPixel'])} rays/pixel/frame "
-                               f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, {args.rng.upper()}, FLAT_CHUNKS semantics",
+                               f"(1024 spp = 16 frames), {int(params['maxBounceCount'])} bounces, {args.rng.upper()}, {'BRUTE (diagnostic)' if int(params['intersectMode']) == 1 else 'FLAT_CHUNKS'} semantics",
                    "decomposition": (f"{world} ranks, " + ("interleaved 8-row bands" if banded else "contiguous row strips")
                                      + " + one RCCL gather") if (world > 1 or force_dist) else
                                     (f"diagnostic: rank 0 of {sim} (its interleaved bands only, no gather)" if sim else "single GPU"),

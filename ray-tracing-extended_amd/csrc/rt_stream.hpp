@@ -44,7 +44,10 @@ struct StreamArgs {
                                 // (the estimator of include/rt.h RT_RNG_PHILOX).  n1 = frames of the launch, n16 = n4 = 0
 };
 
-enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3 };
+// kModeTravStrict: a traversal that evaluates the reference's chunk-box filter at every candidate (see "chunk filter" in k_stream); both
+// traversal modes are the values <= 0 as signed integers: is_trav() is one compare
+enum : uint32_t { kModeTrav = 0, kModeShade = 1, kModeDead = 2, kModeWait = 3, kModeTravStrict = 0xFFFFFFFFu };
+__device__ __forceinline__ bool is_trav(uint32_t mode) { return (int)mode <= 0; }
 constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 
 struct StreamKernArgs { DeviceScene S; FrameArgs F; StreamArgs A; };     // k_stream's argument segment (fresh_kernargs, rt_kernels.hpp)
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
     RT_MARK("end prologue");
     for (;;) {
         RT_MARK("begin head");
-        const int nTrav = __popcll(ballot_(mode == kModeTrav)), nShade = __popcll(ballot_(mode == kModeShade));
+        const int nTrav = __popcll(ballot_(is_trav(mode))), nShade = __popcll(ballot_(mode == kModeShade));
         RT_MARK("end head");
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
@@ -322,10 +325,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
             const uint32_t W = (uint32_t)p.width;
             bool need_ray = false;                      // a camera ray must be generated
             bool want = false;                          // this lane finished its unit and takes the next one of the group
+            bool retrace = false;                       // the answer of this lane's query failed the chunk filter: same ray again, strictly
             if (mode == kModeShade) {
                 need_ray = fresh;
                 fresh = false;
                 bool path_done = false;
+                // ---- chunk filter (RT_INTERSECT_FLAT_CHUNKS, the literal result): the reference tests a triangle only when RayBoundingBox of
+                // its chunk passes (:279).  A chunk's box contains its triangles, so the test can only fail by rounding (or for boxes that
+                // were uploaded too tight) — evaluating it for every candidate of every ray cost 9 % of the frame.  Instead the traversal
+                // takes the closest triangle over ALL chunks and the test is made once, here, for the answer: if it passes, the answer is
+                // the closest admissible hit as well (the minimum over a superset that lies in the subset); if not, the ray is traced
+                // again with the filter at every candidate (kModeTravStrict) — the old behaviour, for the rare ray that needs it.
+                if constexpr (TRI) {
+                    if (live && best.id != kNone && (best.id & kTriBit) && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
+                        const uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3].w);
+                        const float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
+                        if (!ray_bounding_box(o, slab.inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z))) { retrace = true; live = false; }
+                    }
+                }
                 if (live) {
                     if (best.id != kNone) {
                         // ---- hit: Trace :309-343
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                     {
                         // ---- new closest-hit query: CalculateRayCollision :256-273 (spheres in buffer order)
                         RT_REGION_BEGIN(setup);
-                        cnt.rays++;
+                        if (!retrace) cnt.rays++;
                         best.t = INF; best.id = kNone;
                         const float a = rtm::dot(d, d);
                         const SphereA sa = sphere_a(a);
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                             RT_REGION_BEGIN(setup_spheres);         // (one execution per sphere and SHADE pass)
                             const float4 s = S.sph_geom[i];
                             float dst;
-                            if (COUNT) cnt.sph++;
+                            if (COUNT && !retrace) cnt.sph++;          // (a strict second traversal is the same ray: counted once)
                             if (ray_sphere(o, d, sa, rtm::mk(s.x, s.y, s.z), s.w, dst) && dst < best.t) { best.t = dst; best.id = (uint32_t)i; }
                             RT_REGION_END(setup_spheres);
                         }
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                         if constexpr (TRI) {
                             if (S.nn > 0 && traceable) {
                                 slab = make_slab<H>(o, d);                              // RayBoundingBox :179
-                                cur = 0; top = stk0; mode = kModeTrav;
+                                cur = 0; top = stk0; mode = retrace ? kModeTravStrict : kModeTrav;
                                 // A camera ray of a pixel with a candidate list (rt_primary.hpp: every triangle a ray through the pixel's footprint can hit
                                 // first lies in these <= 4 leaves) starts with the leaves on its stack instead of the root: no node step at all.
                                 if (F.primary != nullptr && need_ray) {
@@ -567,10 +584,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                     // (cur is an internal node only while the lane traverses: every exit from kModeTrav sets cur = kNone)
                     const int nAtNode = __popcll(ballot_((int)cur >= 0));
                     if (nAtNode == 0) { RT_REGION_END(nodeloop); break; }
-                    if (nAtNode < A.node_min && ballot2_(mode == kModeTrav, (int)cur < 0) != 0) { RT_REGION_END(nodeloop); break; }   // few descenders: serve the leaves first
+                    if (nAtNode < A.node_min && ballot2_(is_trav(mode), (int)cur < 0) != 0) { RT_REGION_END(nodeloop); break; }   // few descenders: serve the leaves first
 #ifdef RT_DIAG_IDLE      // diagnostic build only: what the lanes that sit out a node step are waiting for (counters 3 / 4 re-used)
                     if (COUNT) {
-                        if (mode == kModeTrav && (int)cur < 0) cnt.phase_lanes[3]++;          // holds a leaf
+                        if (is_trav(mode) && (int)cur < 0) cnt.phase_lanes[3]++;          // holds a leaf
                         if (mode == kModeShade) cnt.phase_lanes[4]++;                          // query complete, waits for SHADE
                         if (lane == 0) { cnt.phase_execs[3]++; cnt.phase_execs[4]++; }
                     }
@@ -620,7 +637,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                     }
                     RT_REGION_END(nodeloop);
                 }
-                if (mode == kModeTrav && (int)cur < 0) {            // a leaf = kLeafBit | first << 2 | count-1
+                if (is_trav(mode) && (int)cur < 0) {            // a leaf = kLeafBit | first << 2 | count-1
                     RT_REGION_BEGIN(leaf);
                     uint32_t ti = (cur & 0x7FFFFFFFu) >> 2;
                     const uint32_t last = ti + (cur & 3u);
@@ -648,8 +665,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                                 take = oc < ob;
                                 RT_REGION_END(tri_tie);
                             }
-                            if (take && F.p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
-                                // the reference only reaches this triangle if its chunk's box test passes (:279)
+                            if (take && mode == kModeTravStrict) {
+                                // the reference only reaches this triangle if its chunk's box test passes (:279) — evaluated here only on the
+                                // second, strict traversal of a ray whose first answer failed it in SHADE (see "chunk filter" there)
                                 RT_REGION_BEGIN(tri_chunk);
                                 uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
                                 float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
@@ -666,7 +684,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                     RT_REGION_END(leaf);
                 }
                 RT_REGION_END(burstiter);
-                if (ballot_(mode == kModeTrav) == 0) break;
+                if (ballot_(is_trav(mode)) == 0) break;
                 if ((int)__popcll(ballot_(mode == kModeShade)) >= thr) break;
             }
             RT_REGION_END(burst);
