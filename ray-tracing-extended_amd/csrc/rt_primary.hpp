@@ -10,10 +10,10 @@
 //      traversal (float, f16 nodes, LDS stack): these hits only NOMINATE triangles, nothing is concluded from them;
 //   2. a triangle T that ALL FOUR corner rays hit with barycentrics >= kBaryMargin and determinant >= kDetMargin is hit by every ray
 //      of the footprint (a central projection maps the square's convex hull onto a convex region of T's plane inside T), no farther
-//      than the farthest corner hit, and robustly so in the kernels' float arithmetic (the margins dwarf its rounding errors; with the
-//      reference's chunk cull in force, RT_INTERSECT_FLAT_CHUNKS, T's chunk box must pass RayBoundingBox with the same kind of margin
-//      for all four corners): the closest hit of every camera ray of the pixel therefore lies within t_max = that distance (+ margin).
-//      Without such a T, t_max = infinity;
+//      than the farthest corner hit, and robustly so in the kernels' float arithmetic (the margins dwarf its rounding errors): the
+//      closest hit of every camera ray of the pixel OVER ALL TRIANGLES therefore lies within t_max = that distance (+ margin) — which
+//      is what k_stream's first traversal of a ray looks for: the reference's chunk cull (RT_INTERSECT_FLAT_CHUNKS) is applied to its
+//      answer in SHADE, and a ray whose answer fails it is traced again from the root, without a list.  Without such a T, t_max = infinity;
 //   3. every leaf whose (padded) box meets the footprint's frustum — four planes through the camera position — within t_max is a
 //      candidate; a triangle in any other leaf cannot be the closest hit of a ray of this pixel: a hit the kernels' arithmetic accepts
 //      lies inside its leaf's padded box (that is what the padding is for, bvh.cpp pad_box), and the ray lies inside the frustum.
@@ -42,27 +42,6 @@ __device__ __forceinline__ D3 operator*(D3 a, double s) { return { a.x * s, a.y 
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ D3 cross(D3 a, D3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
 
-// The reference's RayBoundingBox (:177-187) for the chunk of a nominated triangle, in double and with margins: true only when the float
-// evaluation passes for certain — every near plane of one axis lies before every far plane of the OTHER axes by a margin (the two
-// planes of one axis are compared exactly in float as well: min and max of the same two numbers).
-__device__ __forceinline__ bool chunk_box_passes_for_certain(const float4 bmn, const float4 bmx, D3 o, D3 d)
-{
-    const double lo[3] = { bmn.x, bmn.y, bmn.z }, hi[3] = { bmx.x, bmx.y, bmx.z }, oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-    double t1[3], t2[3];
-    for (int a = 0; a < 3; ++a) {
-        if (!(fabs(dd[a]) > 1e-12)) {                                   // (nearly) parallel to the slab: inside it for certain, or no conclusion
-            if (!(oo[a] > lo[a] + 1e-6 * (1.0 + fabs(lo[a])) && oo[a] < hi[a] - 1e-6 * (1.0 + fabs(hi[a])))) return false;
-            t1[a] = -1e300; t2[a] = 1e300;
-            continue;
-        }
-        const double ta = (lo[a] - oo[a]) / dd[a], tb = (hi[a] - oo[a]) / dd[a];
-        t1[a] = fmin(ta, tb); t2[a] = fmax(ta, tb);
-    }
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b)
-            if (a != b && !(t1[a] + 1e-5 * (1.0 + fabs(t1[a])) <= t2[b])) return false;
-    return true;
-}
 
 struct PrimaryArgs {
     rt_params p;
@@ -158,10 +137,6 @@ __global__ __launch_bounds__(64) void k_primary_lists(rtk::DeviceScene S, Primar
                 const D3 dq = unit[q];
                 all = tri_hit(S.tri_geo, (uint32_t)hit[c], pos, dq, t, u, v, det)
                       && det >= kDetMargin && u >= kBaryMargin && v >= kBaryMargin && 1.0 - u - v >= kBaryMargin && t > 0.0;
-                if (all && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
-                    const uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)hit[c] * 3].w);
-                    all = chunk_box_passes_for_certain(S.chunk_box[(size_t)chunk * 2], S.chunk_box[(size_t)chunk * 2 + 1], pos, dq);
-                }
                 far = fmax(far, t);
             }
             if (all) tmax = fmin(tmax, far * kTmaxMargin);
