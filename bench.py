@@ -431,7 +431,6 @@ def main():
                 names = sv.get("regions") or []
                 ex = {n: float(sc["regionExecs"][i]) for i, n in enumerate(names) if i < len(sc["regionExecs"])}
                 ex["loop"] = ex.get("shade", 0.0) + ex.get("burst", 0.0) + ex.get("fetch", 0.0)          # one pass of the persistent loop's head and latch per region entered
-                ex["head"] = ex["loop"]
                 ex["prologue"] = ex["epilogue"] = 0.0                                                    # once per wave: a few thousand waves per launch
                 dof_on = not (float(params["defocusStrength"]) == 0.0)                                   # (the host's fixed_origin decision, wave-uniform in the kernel)
                 ex["camera_dof"] = ex.get("camera", 0.0) if dof_on else 0.0

@@ -107,7 +107,7 @@ __device__ __forceinline__ unsigned long long ballot2_(bool a, bool b) { return 
 // RT_REGION_BEGIN and RT_REGION_END in the source; the innermost region owns an instruction.  `loop` is everything outside the others.
 #define RT_REGION_LIST(X) X(loop) X(fetch) X(shade) X(hit) X(hit_sphere) X(hit_checker) X(hit_scatter) X(env) X(env_sun) X(camera) X(pixel_done) \
                           X(take) X(refill) X(setup) X(setup_list) X(burst) X(burstiter) X(nodeloop) X(node) X(node_spill) X(node_pop) X(leaf) X(tri) \
-                          X(tri_accept) X(tri_tie) X(tri_chunk) X(prologue) X(head) X(epilogue) X(camera_dof) X(camera_focus) X(setup_spheres)
+                          X(tri_accept) X(tri_tie) X(tri_chunk) X(prologue) X(verify) X(epilogue) X(camera_dof) X(camera_focus) X(setup_spheres)
 enum Region : int {
 #define RT_X(NAME) R_##NAME,
     RT_REGION_LIST(RT_X)

@@ -213,9 +213,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
 
     RT_MARK("end prologue");
     for (;;) {
-        RT_MARK("begin head");
         const int nTrav = __popcll(ballot_(is_trav(mode))), nShade = __popcll(ballot_(mode == kModeShade));
-        RT_MARK("end head");
         if (nTrav + nShade == 0) {
             if (!A.tile_sync) break;                                                  // every lane is dead
             RT_REGION_BEGIN(fetch);
@@ -338,9 +336,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                 // again with the filter at every candidate (kModeTravStrict) — the old behaviour, for the rare ray that needs it.
                 if constexpr (TRI) {
                     if (live && best.id != kNone && (best.id & kTriBit) && p.intersectMode == RT_INTERSECT_FLAT_CHUNKS) {
+                        RT_REGION_BEGIN(verify);
                         const uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)(best.id & ~kTriBit) * 3].w);
                         const float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];
                         if (!ray_bounding_box(o, slab.inv, rtm::mk(bmn.x, bmn.y, bmn.z), rtm::mk(bmx.x, bmx.y, bmx.z))) { retrace = true; live = false; }
+                        RT_REGION_END(verify);
                     }
                 }
                 if (live) {
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(stream_w
                             if (take && mode == kModeTravStrict) {
                                 // the reference only reaches this triangle if its chunk's box test passes (:279) — evaluated here only on the
                                 // second, strict traversal of a ray whose first answer failed it in SHADE (see "chunk filter" there)
+                                RT_RARE_PATH();
                                 RT_REGION_BEGIN(tri_chunk);
                                 uint32_t chunk = __float_as_uint(S.tri_nrm[(size_t)ti * 3].w);
                                 float4 bmn = S.chunk_box[(size_t)chunk * 2], bmx = S.chunk_box[(size_t)chunk * 2 + 1];

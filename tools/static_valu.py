@@ -148,8 +148,13 @@ def count(lines, marked):
         stack = list(stack)
         # a block that is entered only by falling through a conditional branch (`; %bb.N:`) and whose first marker opens a region is the
         # body of the `if` that the region starts: the instructions the scheduler placed in front of the comment are the region's too
-        first = next((re.match(r"^; RTMARK (begin|end) (\w+)", t) for t in b["lines"] if t.startswith("; RTMARK")), None)
+        marks = [re.match(r"^; RTMARK (begin|end) (\w+)", t) for t in b["lines"] if t.startswith("; RTMARK")]
+        first = marks[0] if marks else None
         lead = first.group(2) if marked and first and first.group(1) == "begin" and b["label"].startswith("%bb") else None
+        # a block whose only comments are `begin X` ... `end X` is the whole body of the `if` that X wraps (the scheduler moves the
+        # body's arithmetic across both comments: they have no operands): every instruction of the block is X's
+        whole = (marks[0].group(2) if marked and len(marks) == 2 and marks[0].group(1) == "begin" and marks[1].group(1) == "end"
+                 and marks[0].group(2) == marks[1].group(2) and not b.get("option") else None)
         for t in b["lines"]:
             m = re.match(r"^; RTMARK (begin|end) (\w+)", t)
             if m and marked:
@@ -169,7 +174,7 @@ def count(lines, marked):
             if not tally or t.startswith((";", ".")):
                 continue
             k = kind(t.split()[0])
-            r = b.get("option") or lead or stack[-1]
+            r = b.get("option") or whole or lead or stack[-1]
             if r == "loop" and not b.get("in_loop"):            # straight-line code outside the persistent loop: before it or after it
                 r = "epilogue" if b.get("after_loop") else "prologue"
             (cold if b.get("cold") else regions[r])[k] += 1
