@@ -32,8 +32,8 @@ bench)
   python tools/bench_geometry.py > $O/bench_geometry_r04.json 2>> $O/bvh.err
   python tools/bsum.py $O/bench_r04_config*.json $O/bench_r04_rank0of*.json $O/bench_r04_gloo2_one_gpu.json ;;
 validate)
-  timeout -k 10 560 python tools/validate_headline.py 16 > $O/validate_headline_r03.txt 2>&1; tail -2 $O/validate_headline_r03.txt
-  timeout -k 10 560 python tools/validate_headline.py 16 philox > $O/validate_headline_r03_philox.txt 2>&1; tail -2 $O/validate_headline_r03_philox.txt ;;
+  timeout -k 10 560 python tools/validate_headline.py 16 > $O/validate_headline_r04.txt 2>&1; tail -2 $O/validate_headline_r04.txt
+  timeout -k 10 560 python tools/validate_headline.py 16 philox > $O/validate_headline_r04_philox.txt 2>&1; tail -2 $O/validate_headline_r04_philox.txt ;;
 summaries)   # (here, after `profiles` has come back: gpurun_out/prof_r04c* -> profiles/*_summary.{json,md} + profiles/pmc_table.json)
   python tools/summarize_profile.py r04c k_stream && python tools/make_pmc_table.py r04c 3 1920 1080 64 16
   python tools/summarize_profile.py r04c_philox k_stream && python tools/make_pmc_table.py r04c_philox 3 1920 1080 64 16 _philox
