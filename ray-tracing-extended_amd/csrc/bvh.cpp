@@ -320,6 +320,23 @@ void build(const float* tri_pos, size_t stride_floats, uint32_t n_tris, float or
             if (B.bn[n].count == 0) { st.push_back({ B.bn[n].left, d + 1 }); st.push_back({ B.bn[n].right, d + 1 }); }
         }
     }
+    if (g_reinsert_passes > 0 && tuning.collapse_dp != 0 && !B.bn.empty()) {
+        // the cost-driven collapse makes leaves of whole binary subtrees and takes their triangles as ONE range of the index array —
+        // true for the tree the split search built, not after the insertion passes have moved subtrees around: put the index array
+        // back into the tree's depth-first order (found by the randomised differential test: three triangles in no leaf, three twice)
+        std::vector<uint32_t> nidx; nidx.reserve(B.idx.size());
+        std::vector<int> st; st.push_back(root);
+        while (!st.empty()) {
+            const int n = st.back(); st.pop_back();
+            BNode& N = B.bn[n];
+            if (N.count) {
+                const uint32_t nf = (uint32_t)nidx.size();
+                for (uint32_t i = N.first; i < N.first + N.count; ++i) nidx.push_back(B.idx[i]);
+                N.first = nf;
+            } else { st.push_back(N.right); st.push_back(N.left); }
+        }
+        B.idx.swap(nidx);
+    }
     out.order = B.idx;
     out.magnitude = G;
     out.depth = B.depth;
