@@ -60,7 +60,10 @@ static_assert(offsetof(StreamKernArgs, F) == ((sizeof(DeviceScene) + 7) & ~size_
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES 6           // waves per SIMD of the PCG / f16-node instantiation (see below)
 #endif
-constexpr int stream_waves(bool count, bool philox, bool h, bool tri) { return count ? 3 : !tri ? 6 : (philox || !h) ? 5 : RT_STREAM_WAVES; }     // (counting build: 47 counters in registers)
+#ifndef RT_STREAM_WAVES_PHILOX
+#define RT_STREAM_WAVES_PHILOX 5    // (six waves = 80 VGPRs: 34 of them spilled, 13.9 against 16.9 Grays/s — round 4, one box, interleaved)
+#endif
+constexpr int stream_waves(bool count, bool philox, bool h, bool tri) { return count ? 3 : !tri ? 6 : philox ? RT_STREAM_WAVES_PHILOX : !h ? 5 : RT_STREAM_WAVES; }     // (counting build: 47 counters in registers)
 template <bool COUNT, bool PHILOX = false, bool H = false, bool TRI = true>
 // Waves per SIMD.  The kernel hides its memory and LDS latencies with resident waves.  Round 2 chose five (96 VGPRs; six = 80 VGPRs spilled
 // 26 dwords and lost: 14.18 against 14.70 Grays/s).  Round 4: compiled without structurizing uniform regions (__graft_entry__.py
