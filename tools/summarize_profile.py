@@ -14,10 +14,22 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 out = {"tag": tag, "kernel_filter": kernel_filter}
 
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+
+def newest(pattern):
+    """one file per pass directory: the newest (gpurun MERGES a call's output into gpurun_out/, so a pass that was run twice has the
+    files of both runs there — averaging them would mix two builds)"""
+    best = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     rows = list(csv.DictReader(open(f)))
     out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
+for f in newest(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         if kernel_filter in r["Kernel_Name"]:
             out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
@@ -25,7 +37,7 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
             break
 
 counters = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if kernel_filter not in r["Kernel_Name"]:
             continue
