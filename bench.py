@@ -38,7 +38,7 @@ VMEM_CYCLES_PER_WAVE_LOAD = 16.2     # tools/ubench/vmem_rate.hip (profiles/uben
 
 
 def csrc_sha16():
-    """fingerprint of the kernel sources (csrc/ + include/rt.h): stamps the committed PMC passes (profiles/pmc_table.json), so that a
+    """fingerprint of the kernel sources (csrc/ + include/rt.h + the build flags of __graft_entry__.py): stamps the committed PMC passes (profiles/pmc_table.json), so that a
     pass taken on other kernels than the ones running is flagged instead of silently multiplied with a live time"""
     import hashlib
     h = hashlib.sha256()
@@ -47,6 +47,11 @@ def csrc_sha16():
         if f.endswith((".hpp", ".hip", ".cpp", ".h")):
             h.update(f.encode()); h.update(open(os.path.join(base, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "rt.h"), "rb").read())
+    try:                                    # the compiler flags are part of what runs (round 4: two -mllvm flags were worth 4.6 %)
+        import __graft_entry__ as g
+        h.update(" ".join(list(g.HIPCC_FLAGS) + list(g.STREAM_TU_FLAGS)).encode())
+    except Exception:
+        pass
     return h.hexdigest()[:16]
 
 

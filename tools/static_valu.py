@@ -46,6 +46,7 @@ def csrc_sha16():
         if f.endswith((".hpp", ".hip", ".cpp", ".h")):
             h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "rt.h"), "rb").read())
+    h.update(" ".join(list(g.HIPCC_FLAGS) + list(g.STREAM_TU_FLAGS)).encode())          # (as bench.csrc_sha16)
     return h.hexdigest()[:16]
 
 
