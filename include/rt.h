@@ -248,7 +248,7 @@ int rt_read_world_geometry(rt_ctx* ctx, rt_triangle* tris_out, int n_tris, rt_me
  *   "stream_tile"     k_stream: frames interleaved in a wave, as log2: 0 = 8x8 pixels of one frame, 2 = 4x4 pixels x 4 frames of the
  *                     launch, 4 = 2x2 pixels x 16 frames (default; launches shorter than the group fall back to 8x8 x 1)
  *   "device_bvh"      1 = build the BVH on the device (Morton order, PLOC clustering, sweep-SAH treelet passes, breadth-first collapse to
- *                     4-wide nodes: 100k triangles in 2.5 ms, 1M in 5.4 ms, traced within 1 % of / 2 % faster than the host tree), 0 = the
+ *                     4-wide nodes: 100k triangles in 2.5 ms, 1M in 5.4 ms, traced within about 1 % / within -4 .. +2 % of the host tree), 0 = the
  *                     host's binned-SAH builder (50 ms / 600 ms), -1 (default) = device for rt_upload_local_meshes (meshes that move) and
  *                     for a world-space scene that is uploaded again within 16 traced frames of its last build (the reference's way of
  *                     animating: everything re-sent every frame), host for the first build of a world-space scene
