@@ -8,8 +8,20 @@ int main(int argc, char** argv) {
     uint32_t n = v.size() / 9;
     // the API filters triangles with non-finite positions? emulate: pass all
     rtbvh::Bvh b; rtbvh::Tuning t; t.reinsert_passes = argc > 2 ? atoi(argv[2]) : 0;
+    t.collapse_dp = argc > 3 ? atoi(argv[3]) : 0; t.max_leaf = argc > 4 ? atoi(argv[4]) : 2;
     rtbvh::build(v.data(), 9, n, 10.0f, t, b);
     printf("tris %u nodes %zu maxStack %d depth %d\n", n, b.nodes.size(), b.maxStack, b.depth);
+    {   // every triangle in exactly one leaf (the cost-driven collapse after insertion passes once lost some: round 4)
+        std::vector<int> in_leaf(n, 0);
+        for (const rtbvh::Node4& N : b.nodes)
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = N.child[k];
+                if (c == rtbvh::kEmpty || !(c & rtbvh::kLeafBit)) continue;
+                const uint32_t first = (c & 0x7FFFFFFFu) >> 2, cnt = (c & 3u) + 1;
+                for (uint32_t i = first; i < first + cnt; ++i) { if (i >= b.order.size() || b.order[i] >= n) return 6; in_leaf[b.order[i]]++; }
+            }
+        for (uint32_t i = 0; i < n; ++i) if (in_leaf[i] != 1) return 7;
+    }
     // the device builder's top of the tree: the same split search over boxes (here: the triangles' own boxes, NaN / inf included)
     std::vector<float> boxes(6 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i)

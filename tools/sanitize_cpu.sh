@@ -40,6 +40,6 @@ PY
 export ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=halt_on_error=1
 $W/host_harness $W/Chess.unity $W/Knight.unity $W/Suzanne.unity $W/Thumbnail.unity $W/Balls_Outdoors.unity $W/Reflective_Balls.unity
 $W/host_harness $W/mut*.unity | grep -c exception | sed 's/^/mutated scenes rejected with an exception: /'
-for t in 0 4 16 21 33 99; do $W/bvh_harness $W/pos$t.bin 0; $W/bvh_harness $W/pos$t.bin 2; done
+for t in 0 4 16 21 33 99; do $W/bvh_harness $W/pos$t.bin 0; $W/bvh_harness $W/pos$t.bin 2; $W/bvh_harness $W/pos$t.bin 2 1 4; $W/bvh_harness $W/pos$t.bin 0 1 1; $W/bvh_harness $W/pos$t.bin 2 2 4; done
 $W/oracle_harness 0 4 16 21 33 99
 echo "sanitize_cpu: clean"
